@@ -1,0 +1,429 @@
+// C ABI of libmi355pt.so (see include/mi355pt.h).  Host-side state machine of the reference's
+// `Renderer` (src/renderer/mod.rs:91-320) over the HIP device code in kernels.hip.
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mi355pt.h"
+#include "bvh.h"
+#include "gpu.h"
+#include "scene_io.h"
+#include "scene_pack.h"
+
+using namespace pt;
+
+struct mi355pt_scene {
+    Scene scene;
+};
+
+struct mi355pt_ctx {
+    mi355pt_desc desc{};
+    gpu::Device* dev = nullptr;
+    std::string error;
+
+    // host copy of the scene in wire format (SceneBuffers, mod.rs:32-42)
+    std::vector<Sphere32> spheres;
+    std::vector<Vec16> lights, lambertians, metals;
+    std::vector<float> glass;
+    bool have_scene = false;
+    Bvh2 bvh;
+    SceneLayout layout{};
+    bool scene_in_lds = false;
+
+    // camera: CameraConfig (mod.rs:96) or a caller-supplied uniform
+    bool have_camera = false;
+    bool camera_from_config = false;
+    CameraSettings cam_settings;
+    Camera64 camera{};
+
+    Settings settings;
+    uint32_t width = 0, height = 0;
+    int32_t frames = -1;  // Renderer::samples (mod.rs:102,132)
+    bool dirty = true;    // mod.rs:103,133
+    uint32_t seed_index = 0;
+    gpu::RenderStats stats;
+};
+
+namespace {
+
+std::string g_create_error;
+
+int fail(mi355pt_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+// Builds (or converts) the tree, packs the device blob and uploads it.  ref_nodes may be null.
+int install_tree(mi355pt_ctx* c, const Node48* ref_nodes, size_t n_ref_nodes) {
+    SceneArrays a;
+    a.spheres = c->spheres.data(), a.n_spheres = c->spheres.size();
+    a.lights = c->lights.data(), a.n_lights = c->lights.size();
+    a.lambertians = c->lambertians.data(), a.n_lambertians = c->lambertians.size();
+    a.metals = c->metals.data(), a.n_metals = c->metals.size();
+    a.glass = c->glass.data(), a.n_glass = c->glass.size();
+    std::string err;
+    std::vector<char> blob;
+    c->have_scene = false;
+    if (!pack_scene(a, c->desc.bvh_mode == MI355PT_BVH_REFERENCE, ref_nodes, n_ref_nodes, blob, c->layout, c->bvh, err))
+        return fail(c, MI355PT_ERR_ARG, err);
+    if (!gpu::upload_scene(c->dev, blob.data(), c->layout, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    c->have_scene = true;
+    c->dirty = true;
+    return MI355PT_OK;
+}
+
+void rebuild_camera(mi355pt_ctx* c) {
+    if (c->camera_from_config) {
+        // aspect = width as f32 / height as f32 (mod.rs:115,164)
+        float aspect = (float)c->width / (float)c->height;
+        camera_build(c->cam_settings.pos, c->cam_settings.yaw, c->cam_settings.pitch, c->cam_settings.vfov, aspect,
+                     c->camera);
+    }
+}
+
+void copy_err(const std::string& e, char* buf, size_t len) {
+    if (!buf || !len) return;
+    size_t n = e.size() < len - 1 ? e.size() : len - 1;
+    memcpy(buf, e.data(), n);
+    buf[n] = 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mi355pt_create(const mi355pt_desc* desc, mi355pt_ctx** out) {
+    if (!desc || !out) return fail(nullptr, MI355PT_ERR_ARG, "create: null argument");
+    *out = nullptr;
+    if (desc->width == 0 || desc->height == 0) return fail(nullptr, MI355PT_ERR_ARG, "create: zero image size");
+    if (desc->bvh_mode > MI355PT_BVH_REFERENCE) return fail(nullptr, MI355PT_ERR_ARG, "create: unknown bvh_mode");
+    mi355pt_ctx* c = new (std::nothrow) mi355pt_ctx();
+    if (!c) return fail(nullptr, MI355PT_ERR_NOMEM, "create: out of memory");
+    c->desc = *desc;
+    std::string err;
+    if (!gpu::create(desc->device, desc->stream, &c->dev, err)) {
+        delete c;
+        return fail(nullptr, MI355PT_ERR_DEVICE, err);
+    }
+    c->width = desc->width, c->height = desc->height;
+    if (!gpu::resize(c->dev, c->width, c->height, err)) {
+        gpu::destroy(c->dev);
+        delete c;
+        return fail(nullptr, MI355PT_ERR_DEVICE, err);
+    }
+    *out = c;
+    return MI355PT_OK;
+}
+
+void mi355pt_destroy(mi355pt_ctx* ctx) {
+    if (!ctx) return;
+    gpu::destroy(ctx->dev);
+    delete ctx;
+}
+
+const char* mi355pt_last_error(const mi355pt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int mi355pt_set_scene(mi355pt_ctx* c, const void* spheres32, size_t n_spheres, const void* lights16, size_t n_lights,
+                      const void* lambertians16, size_t n_lambertians, const void* metals16, size_t n_metals,
+                      const void* glass4, size_t n_glass) {
+    if (!c) return MI355PT_ERR_ARG;
+    {
+        SceneArrays a;
+        a.spheres = static_cast<const Sphere32*>(spheres32), a.n_spheres = n_spheres;
+        a.lights = static_cast<const Vec16*>(lights16), a.n_lights = n_lights;
+        a.lambertians = static_cast<const Vec16*>(lambertians16), a.n_lambertians = n_lambertians;
+        a.metals = static_cast<const Vec16*>(metals16), a.n_metals = n_metals;
+        a.glass = static_cast<const float*>(glass4), a.n_glass = n_glass;
+        std::string err;
+        if (!validate_scene(a, err)) return fail(c, MI355PT_ERR_ARG, err);
+    }
+    const Sphere32* sp = static_cast<const Sphere32*>(spheres32);
+    c->have_scene = false;
+    c->spheres.assign(sp, sp + n_spheres);
+    auto vec16 = [](const void* p, size_t n) {
+        const Vec16* v = static_cast<const Vec16*>(p);
+        return n ? std::vector<Vec16>(v, v + n) : std::vector<Vec16>();
+    };
+    c->lights = vec16(lights16, n_lights);
+    c->lambertians = vec16(lambertians16, n_lambertians);
+    c->metals = vec16(metals16, n_metals);
+    const float* g = static_cast<const float*>(glass4);
+    c->glass = n_glass ? std::vector<float>(g, g + n_glass) : std::vector<float>();
+    return install_tree(c, nullptr, 0);
+}
+
+int mi355pt_set_bvh(mi355pt_ctx* c, const void* nodes48, size_t n_nodes) {
+    if (!c) return MI355PT_ERR_ARG;
+    if (c->spheres.empty()) return fail(c, MI355PT_ERR_STATE, "set_bvh: call set_scene first");
+    if (!nodes48) return fail(c, MI355PT_ERR_ARG, "set_bvh: null nodes");
+    return install_tree(c, static_cast<const Node48*>(nodes48), n_nodes);
+}
+
+int mi355pt_set_camera(mi355pt_ctx* c, const void* camera64) {
+    if (!c || !camera64) return MI355PT_ERR_ARG;
+    memcpy(&c->camera, camera64, 64);
+    c->camera_from_config = false;
+    c->have_camera = true;
+    c->dirty = true;
+    return MI355PT_OK;
+}
+
+int mi355pt_set_camera_config(mi355pt_ctx* c, const float pos[3], float yaw_deg, float pitch_deg, float vfov_deg) {
+    if (!c || !pos) return MI355PT_ERR_ARG;
+    memcpy(c->cam_settings.pos, pos, 12);
+    c->cam_settings.yaw = yaw_deg, c->cam_settings.pitch = pitch_deg, c->cam_settings.vfov = vfov_deg;
+    c->camera_from_config = true;
+    c->have_camera = true;
+    rebuild_camera(c);
+    c->dirty = true;
+    return MI355PT_OK;
+}
+
+int mi355pt_get_camera(const mi355pt_ctx* c, void* out) {
+    if (!c || !out || !c->have_camera) return MI355PT_ERR_ARG;
+    memcpy(out, &c->camera, 64);
+    return MI355PT_OK;
+}
+
+int mi355pt_set_settings(mi355pt_ctx* c, int32_t samples, int32_t depth) {
+    if (!c) return MI355PT_ERR_ARG;
+    if (samples < 1) return fail(c, MI355PT_ERR_ARG, "set_settings: samples must be >= 1");
+    c->settings.samples = samples;
+    c->settings.depth = depth;
+    return MI355PT_OK;
+}
+
+int mi355pt_resize(mi355pt_ctx* c, uint32_t width, uint32_t height) {
+    if (!c) return MI355PT_ERR_ARG;
+    std::string err;
+    if (!gpu::resize(c->dev, width, height, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    c->width = width, c->height = height;
+    c->dirty = true;
+    return MI355PT_OK;
+}
+
+int mi355pt_clear(mi355pt_ctx* c) {
+    if (!c) return MI355PT_ERR_ARG;
+    std::string err;
+    rebuild_camera(c);
+    if (!gpu::clear(c->dev, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    c->dirty = false;
+    c->frames = 0;
+    c->seed_index = 0;
+    c->stats = gpu::RenderStats{};
+    return MI355PT_OK;
+}
+
+int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+    if (!c) return MI355PT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
+    if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
+    if (c->dirty) {  // mod.rs:169-195
+        int r = mi355pt_clear(c);
+        if (r != MI355PT_OK) return r;
+    }
+    if (n_frames == 0) return MI355PT_OK;
+    std::vector<uint32_t> own;
+    if (!seeds) {
+        own.resize(n_frames);
+        for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
+        seeds = own.data();
+    }
+    gpu::RenderConfig cfg;
+    cfg.samples = c->settings.samples;
+    cfg.depth = c->settings.depth;
+    cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
+    cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
+    std::string err;
+    if (!gpu::render(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    c->frames += (int32_t)n_frames;
+    c->seed_index += n_frames;
+    return MI355PT_OK;
+}
+
+int32_t mi355pt_frames(const mi355pt_ctx* c) { return c ? c->frames : -1; }
+
+int mi355pt_read_accum(mi355pt_ctx* c, float* rgba, size_t n_floats) {
+    if (!c || !rgba) return MI355PT_ERR_ARG;
+    std::string err;
+    if (!gpu::read_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
+    return MI355PT_OK;
+}
+
+int mi355pt_write_accum(mi355pt_ctx* c, const float* rgba, size_t n_floats, int32_t frames) {
+    if (!c || !rgba) return MI355PT_ERR_ARG;
+    std::string err;
+    if (!gpu::write_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
+    c->frames = frames;
+    c->dirty = false;
+    return MI355PT_OK;
+}
+
+int mi355pt_to_rgb8(mi355pt_ctx* c, int32_t frames, uint8_t* rgb, size_t n_bytes) {
+    if (!c || !rgb) return MI355PT_ERR_ARG;
+    if (n_bytes != (size_t)c->width * c->height * 3) return fail(c, MI355PT_ERR_ARG, "to_rgb8: n_bytes must be 3 * width * height");
+    if (frames < 1) return fail(c, MI355PT_ERR_ARG, "to_rgb8: frames must be >= 1");
+    std::vector<float> acc((size_t)c->width * c->height * 4);
+    std::string err;
+    if (!gpu::read_accum(c->dev, acc.data(), acc.size(), err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    postprocess_rgb8(acc.data(), c->width, c->height, frames, rgb);
+    return MI355PT_OK;
+}
+
+int mi355pt_save_png(mi355pt_ctx* c, int32_t frames, const char* path) {
+    if (!c || !path) return MI355PT_ERR_ARG;
+    std::vector<uint8_t> rgb((size_t)c->width * c->height * 3);
+    int r = mi355pt_to_rgb8(c, frames, rgb.data(), rgb.size());
+    if (r != MI355PT_OK) return r;
+    std::string err;
+    if (!write_png_rgb8(path, rgb.data(), c->width, c->height, err)) return fail(c, MI355PT_ERR_IO, err);
+    return MI355PT_OK;
+}
+
+int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
+    if (!c || !out) return MI355PT_ERR_ARG;
+    memset(out, 0, sizeof *out);
+    out->paths = c->stats.paths, out->rays = c->stats.rays;
+    out->nodes = c->stats.nodes, out->tests = c->stats.tests, out->accepted = c->stats.accepted;
+    for (int k = 0; k < 5; k++) out->bounces[k] = c->stats.bounces[k];
+    out->render_ms = c->stats.render_ms, out->resolve_ms = c->stats.resolve_ms;
+    out->launches = c->stats.launches;
+    out->bvh_nodes = (uint32_t)c->bvh.nodes.size();
+    out->bvh_depth = c->bvh.max_depth;
+    out->scene_bytes = c->layout.total_bytes;
+    out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
+    return MI355PT_OK;
+}
+
+int mi355pt_accum_device_ptr(mi355pt_ctx* c, void** ptr, void** stream) {
+    if (!c) return MI355PT_ERR_ARG;
+    if (ptr) *ptr = gpu::accum_device_ptr(c->dev);
+    if (stream) *stream = gpu::stream_handle(c->dev);
+    return MI355PT_OK;
+}
+
+// ---- host-side pieces ---------------------------------------------------------------------------
+int mi355pt_camera_build(const float pos[3], float yaw_deg, float pitch_deg, float vfov_deg, float aspect, void* out) {
+    if (!pos || !out) return MI355PT_ERR_ARG;
+    Camera64 c;
+    camera_build(pos, yaw_deg, pitch_deg, vfov_deg, aspect, c);
+    memcpy(out, &c, 64);
+    return MI355PT_OK;
+}
+
+int64_t mi355pt_bvh_build_reference(const void* spheres32, size_t n_spheres, int swap_mode, uint32_t swap_seed,
+                                    void* nodes48_out, size_t cap_nodes) {
+    if (!spheres32 || !nodes48_out || n_spheres > 0x7fffffffull) return MI355PT_ERR_ARG;
+    if (swap_mode < 0 || swap_mode > 2) return MI355PT_ERR_ARG;
+    std::vector<Node48> nodes;
+    std::string err;
+    if (!build_reference(static_cast<const Sphere32*>(spheres32), (uint32_t)n_spheres, swap_mode, swap_seed, nodes, err)) {
+        g_create_error = err;
+        return MI355PT_ERR_ARG;
+    }
+    if (nodes.size() > cap_nodes) return MI355PT_ERR_ARG;
+    memcpy(nodes48_out, nodes.data(), nodes.size() * sizeof(Node48));
+    return (int64_t)nodes.size();
+}
+
+uint32_t mi355pt_frame_seed(uint32_t base_seed, uint32_t frame) { return frame_seed(base_seed, frame); }
+
+int mi355pt_postprocess_rgb8(const float* accum_rgba, uint32_t width, uint32_t height, int32_t frames, uint8_t* rgb) {
+    if (!accum_rgba || !rgb || frames < 1) return MI355PT_ERR_ARG;
+    postprocess_rgb8(accum_rgba, width, height, frames, rgb);
+    return MI355PT_OK;
+}
+
+int mi355pt_write_png_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb || !width || !height) return MI355PT_ERR_ARG;
+    std::string err;
+    if (!write_png_rgb8(path, rgb, width, height, err)) {
+        g_create_error = err;
+        return MI355PT_ERR_IO;
+    }
+    return MI355PT_OK;
+}
+
+// ---- RON ------------------------------------------------------------------------------------------
+int mi355pt_scene_parse_ron(const char* text, size_t len, mi355pt_scene** out, char* errbuf, size_t errbuf_len) {
+    if (!text || !out) return MI355PT_ERR_ARG;
+    *out = nullptr;
+    std::unique_ptr<mi355pt_scene> s(new (std::nothrow) mi355pt_scene());
+    if (!s) return MI355PT_ERR_NOMEM;
+    std::string err;
+    if (!parse_scene_ron(std::string(text, len), s->scene, err)) {
+        copy_err(err, errbuf, errbuf_len);
+        return MI355PT_ERR_IO;
+    }
+    *out = s.release();
+    return MI355PT_OK;
+}
+
+int mi355pt_scene_load_ron(const char* path, mi355pt_scene** out, char* errbuf, size_t errbuf_len) {
+    if (!path || !out) return MI355PT_ERR_ARG;
+    *out = nullptr;
+    std::string text, err;
+    if (!read_file(path, text, err)) {
+        copy_err(err, errbuf, errbuf_len);
+        return MI355PT_ERR_IO;
+    }
+    return mi355pt_scene_parse_ron(text.data(), text.size(), out, errbuf, errbuf_len);
+}
+
+mi355pt_scene* mi355pt_scene_default(void) {
+    mi355pt_scene* s = new (std::nothrow) mi355pt_scene();
+    if (s) s->scene = default_scene();
+    return s;
+}
+
+void mi355pt_scene_free(mi355pt_scene* scene) { delete scene; }
+
+size_t mi355pt_scene_array(const mi355pt_scene* s, int which, const void** data) {
+    if (!s) return 0;
+    const void* p = nullptr;
+    size_t n = 0;
+    switch (which) {
+        case 0: p = s->scene.spheres.data(), n = s->scene.spheres.size(); break;
+        case 1: p = s->scene.lights.data(), n = s->scene.lights.size(); break;
+        case 2: p = s->scene.lambertians.data(), n = s->scene.lambertians.size(); break;
+        case 3: p = s->scene.metals.data(), n = s->scene.metals.size(); break;
+        case 4: p = s->scene.glass.data(), n = s->scene.glass.size(); break;
+        default: break;
+    }
+    if (data) *data = p;
+    return n;
+}
+
+void mi355pt_scene_camera(const mi355pt_scene* s, float out6[6]) {
+    if (!s || !out6) return;
+    memcpy(out6, s->scene.camera.pos, 12);
+    out6[3] = s->scene.camera.yaw, out6[4] = s->scene.camera.pitch, out6[5] = s->scene.camera.vfov;
+}
+
+int mi355pt_set_scene_handle(mi355pt_ctx* c, const mi355pt_scene* s) {
+    if (!c || !s) return MI355PT_ERR_ARG;
+    const Scene& sc = s->scene;
+    int r = mi355pt_set_scene(c, sc.spheres.data(), sc.spheres.size(), sc.lights.data(), sc.lights.size(),
+                              sc.lambertians.data(), sc.lambertians.size(), sc.metals.data(), sc.metals.size(),
+                              sc.glass.data(), sc.glass.size());
+    if (r != MI355PT_OK) return r;
+    return mi355pt_set_camera_config(c, sc.camera.pos, sc.camera.yaw, sc.camera.pitch, sc.camera.vfov);
+}
+
+int mi355pt_settings_load_ron(const char* path, int32_t* samples, int32_t* depth, char* errbuf, size_t errbuf_len) {
+    if (!path || !samples || !depth) return MI355PT_ERR_ARG;
+    std::string text, err;
+    Settings s;
+    if (!read_file(path, text, err) || !parse_settings_ron(text, s, err)) {
+        copy_err(err, errbuf, errbuf_len);
+        return MI355PT_ERR_IO;
+    }
+    *samples = s.samples, *depth = s.depth;
+    return MI355PT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,52 @@
+// Host-visible interface of the HIP side (implemented in kernels.hip).  Plain C++ types only.
+#pragma once
+#include <cstdint>
+#include <string>
+
+#include "pt_types.h"
+
+namespace pt {
+namespace gpu {
+
+struct Device;  // one GPU: stream, scene blob, accumulator, sample buffer, work counter
+
+struct RenderStats {
+    uint64_t paths = 0;      // primary rays started (pixel-frames x samples)
+    uint64_t rays = 0;       // closest-hit queries
+    uint64_t nodes = 0;      // interior nodes fetched (two box tests each)   [counting launches only]
+    uint64_t tests = 0;      // sphere tests                                  [counting launches only]
+    uint64_t accepted = 0;   // sphere tests that replaced the closest record [counting launches only]
+    uint64_t bounces[5] = {0, 0, 0, 0, 0};  // light, lambertian, metal, glass, sky  [counting only]
+    double render_ms = 0.0;  // device time of the path kernels (HIP events on the render stream)
+    double resolve_ms = 0.0; // device time of the frame-order accumulation kernels
+    uint32_t launches = 0;
+};
+
+struct RenderConfig {
+    int32_t samples = 1;
+    int32_t depth = 50;
+    bool glass_always_draws = true;
+    bool count = false;       // run the instrumented kernel variant (slower)
+    uint32_t max_batch = 0;   // frames per launch; 0 = choose from the image size
+};
+
+bool create(int device_id, void* stream, Device** out, std::string& err);
+void destroy(Device* d);
+bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err);
+bool resize(Device* d, uint32_t width, uint32_t height, std::string& err);
+bool clear(Device* d, std::string& err);
+// Accumulates n_frames frames (seeds[f] = Globals.seed of frame f) in frame order.
+bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+            RenderStats& stats, std::string& err);
+bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
+bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
+void* accum_device_ptr(Device* d);
+void* stream_handle(Device* d);
+bool synchronize(Device* d, std::string& err);
+int device_id(Device* d);
+bool scene_in_lds(Device* d);
+// Chip facts used by callers to size work and report rooflines.
+bool device_info(Device* d, int* compute_units, int* clock_khz, size_t* lds_per_cu, char name[256]);
+
+}  // namespace gpu
+}  // namespace pt

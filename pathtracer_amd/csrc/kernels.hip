@@ -1,0 +1,576 @@
+// HIP kernels for gfx950 (MI355X) and their launch code.
+//
+//   pt_hash_kernel     per-pixel seed hash (compute.wgsl:392-400), once per resize
+//   pt_render_kernel   persistent path kernel: every lane owns one (pixel, frame) path at a time and
+//                      pulls a new one from a work queue the moment its path ends, so divergent path
+//                      lengths (1..depth+1 rays) never idle a lane; phases per iteration:
+//                      acquire -> camera -> extend (BVH walk) -> scatter
+//   pt_resolve_kernel  adds the per-frame results to the accumulator in frame order
+//                      (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "gpu.h"
+#include "pt_device.h"
+
+namespace pt {
+namespace gpu {
+
+constexpr int BLOCK = 256;             // 4 waves
+constexpr uint32_t CHUNK_UNITS = 4;    // 64-path units taken from the queue per atomic
+
+#define PT_LDS(T) __attribute__((address_space(3))) T
+
+// Scene blob staged in LDS: explicit address space so every fetch is a ds_read.
+struct LdsMem {
+    uint32_t base;
+    template <class T>
+    __device__ __forceinline__ T load(uint32_t off) const {
+        // address-space-qualified loads exist for builtin vector types only; bit-cast to the record
+        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+        if constexpr (sizeof(T) == 16) {
+            w4 v = *reinterpret_cast<const PT_LDS(w4)*>(base + off);
+            return __builtin_bit_cast(T, v);
+        } else if constexpr (sizeof(T) == 8) {
+            w2 v = *reinterpret_cast<const PT_LDS(w2)*>(base + off);
+            return __builtin_bit_cast(T, v);
+        } else {
+            static_assert(sizeof(T) == 4, "LDS loads are 4, 8 or 16 bytes");
+            uint32_t v = *reinterpret_cast<const PT_LDS(uint32_t)*>(base + off);
+            return __builtin_bit_cast(T, v);
+        }
+    }
+};
+// Per-lane traversal stack in LDS, entry-major so that lane l always hits bank l % 64.
+struct LdsStack {
+    uint32_t base;  // byte address of this lane's entry 0
+    __device__ __forceinline__ void push(int sp, int32_t v) const {
+        *reinterpret_cast<PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLOCK * 4u)) = v;
+    }
+    __device__ __forceinline__ int32_t pop(int sp) const {
+        return *reinterpret_cast<const PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLOCK * 4u));
+    }
+};
+
+struct RenderParams {
+    const char* scene;
+    SceneLayout L;
+    Camera64 cam;
+    uint32_t width, height, tiles_x, tiles_per_frame, n_pix;
+    int32_t samples, depth;
+    uint32_t total_units;  // frames in this launch * tiles_per_frame
+    const uint32_t* seeds;       // one per frame of this launch
+    const uint32_t* pixel_hash;  // [n_pix]
+    f4* frame_out;               // [frames][n_pix]: rgb = final_colour / samples, w = rays traced
+    uint32_t* work_counter;
+    unsigned long long* counters;  // nodes, tests, accepted, bounce[5]
+    uint32_t scene_lds_bytes;
+    int32_t glass_always_draws;
+};
+
+__global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= w * h) return;
+    out[i] = pixel_hash(i % w, i / w, w, h);
+}
+
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+template <bool LDS_SCENE, bool COUNT>
+__global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) {
+    extern __shared__ __align__(16) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
+    if (LDS_SCENE) {
+        const f4* src = reinterpret_cast<const f4*>(P.scene);
+        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLOCK)
+        {
+            typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = reinterpret_cast<const w4*>(src)[i];
+        }
+        __syncthreads();
+    }
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, PtrMem>::type;
+    Mem mem;
+    if constexpr (LDS_SCENE) mem.base = lds0;
+    else mem.base = P.scene;
+    LdsStack stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
+
+    const CameraRegs cam = load_camera(P.cam);
+    const float fw = (float)P.width, fh = (float)P.height;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    // lane state
+    bool alive = false, need_ray = false;
+    PathState ps;
+    ps.o = ps.d = ps.colour = mk(0.0f, 0.0f, 0.0f);
+    ps.rng = 1u;
+    ps.bounce = 0;
+    V3 final_colour = mk(0.0f, 0.0f, 0.0f);
+    uint32_t out_index = 0, pxy = 0, nrays = 0;
+    int32_t sample_i = 0;
+    Counters cnt = {0, 0, 0};
+    uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
+
+    // wave state (uniform)
+    uint32_t next = 0, end = 0;
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- acquire: idle lanes take consecutive path ids from the wave's chunk of the queue
+        unsigned long long m = __ballot(!alive);
+        while (m) {
+            if (next == end) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.work_counter, CHUNK_UNITS);
+                base = __shfl(base, 0);
+                if (base >= P.total_units) {
+                    exhausted = true;
+                    break;
+                }
+                next = base * 64u;
+                end = min(base + CHUNK_UNITS, P.total_units) * 64u;
+            }
+            const uint32_t avail = end - next;
+            const uint32_t rank = lane_rank(m);
+            if (!alive && rank < avail) {
+                const uint32_t pid = next + rank;
+                const uint32_t unit = pid >> 6, slot = pid & 63u;
+                const uint32_t frame = unit / P.tiles_per_frame;
+                const uint32_t tile = unit - frame * P.tiles_per_frame;
+                uint32_t px, py;
+                tile_pixel(tile, slot, P.tiles_x, px, py);
+                if (px < P.width && py < P.height) {
+                    const uint32_t pix = py * P.width + px;
+                    ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
+                    out_index = frame * P.n_pix + pix;
+                    pxy = px | (py << 16);
+                    final_colour = mk(0.0f, 0.0f, 0.0f);
+                    sample_i = 0;
+                    nrays = 0;
+                    alive = true;
+                    need_ray = true;
+                }
+            }
+            next += min((uint32_t)__popcll(m), avail);
+            m = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- camera: compute.wgsl:405-413
+        if (alive && need_ray) {
+            ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
+            ps.o = cam.pos;
+            ps.colour = mk(1.0f, 1.0f, 1.0f);
+            ps.bounce = 0;
+            need_ray = false;
+        }
+
+        // ---- extend + scatter
+        if (alive) {
+            Hit hit;
+            closest_hit<Mem, LdsStack, COUNT>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
+            nrays++;
+            V3 radiance;
+            uint32_t mat;
+            const bool done = scatter(mem, P.L, hit, ps, P.depth, P.glass_always_draws != 0, radiance, mat);
+            if (COUNT) {
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (mat == k) ? 1u : 0u;
+            }
+            if (done) {
+                final_colour = final_colour + radiance;
+                sample_i++;
+                if (sample_i < P.samples) {
+                    need_ray = true;
+                } else {
+                    const float fs = (float)P.samples;
+                    f4 o4;
+                    o4.x = final_colour.x / fs;
+                    o4.y = final_colour.y / fs;
+                    o4.z = final_colour.z / fs;
+                    o4.w = (float)nrays;
+                    P.frame_out[out_index] = o4;
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    if (COUNT) {
+        unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
+                                   bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            unsigned long long s = wave_sum(v[k]);
+            if (lane == 0) atomicAdd(&P.counters[k], s);
+        }
+    }
+}
+
+// accum[p] += vec4(frame[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side.
+__global__ void pt_resolve_kernel(f4* accum, const f4* frames, uint32_t n_pix, uint32_t n_frames,
+                                  unsigned long long* ray_total) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long rays = 0;
+    if (i < n_pix) {
+        f4 a = accum[i];
+        for (uint32_t f = 0; f < n_frames; f++) {
+            f4 s = frames[(size_t)f * n_pix + i];
+            a.x += s.x;
+            a.y += s.y;
+            a.z += s.z;
+            a.w += 0.0f;
+            rays += (unsigned long long)s.w;
+        }
+        accum[i] = a;
+    }
+    rays = wave_sum(rays);
+    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(ray_total, rays);
+}
+
+__global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------ host
+struct Device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipDeviceProp_t prop;
+
+    char* scene = nullptr;
+    size_t scene_cap = 0;
+    SceneLayout layout{};
+    bool have_scene = false;
+    bool scene_in_lds = false;
+
+    uint32_t width = 0, height = 0, n_pix = 0;
+    f4* accum = nullptr;
+    uint32_t* pixel_hash = nullptr;
+    f4* frame_buf = nullptr;
+    size_t frame_cap = 0;  // in f4 elements
+    uint32_t* seeds = nullptr;
+    size_t seeds_cap = 0;
+    uint32_t* work_counter = nullptr;  // [1]
+    unsigned long long* counters = nullptr;  // [8] kernel counters + [1] rays
+    std::vector<hipEvent_t> events;
+};
+
+#define PT_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return false;                                                                     \
+        }                                                                                     \
+    } while (0)
+
+bool create(int device_id, void* stream, Device** out, std::string& err) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        err = "no HIP device available (this library has no CPU path)";
+        return false;
+    }
+    if (device_id < 0 || device_id >= n) {
+        err = "device ordinal out of range";
+        return false;
+    }
+    PT_HIP(hipSetDevice(device_id));
+    Device* d = new Device();
+    d->id = device_id;
+    if (hipGetDeviceProperties(&d->prop, device_id) != hipSuccess) {
+        delete d;
+        err = "hipGetDeviceProperties failed";
+        return false;
+    }
+    if (stream) {
+        d->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete d;
+            err = "hipStreamCreate failed";
+            return false;
+        }
+        d->own_stream = true;
+    }
+    if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, 256) != hipSuccess) {
+        destroy(d);
+        err = "hipMalloc failed";
+        return false;
+    }
+    hipMemset(d->counters, 0, 256);
+    *out = d;
+    return true;
+}
+
+void destroy(Device* d) {
+    if (!d) return;
+    hipSetDevice(d->id);
+    if (d->stream) hipStreamSynchronize(d->stream);
+    for (hipEvent_t e : d->events) hipEventDestroy(e);
+    hipFree(d->scene);
+    hipFree(d->accum);
+    hipFree(d->pixel_hash);
+    hipFree(d->frame_buf);
+    hipFree(d->seeds);
+    hipFree(d->work_counter);
+    hipFree(d->counters);
+    if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int device_id(Device* d) { return d->id; }
+bool scene_in_lds(Device* d) { return d->have_scene && d->scene_in_lds; }
+void* accum_device_ptr(Device* d) { return d->accum; }
+void* stream_handle(Device* d) { return d->stream; }
+
+bool device_info(Device* d, int* cus, int* clock_khz, size_t* lds_per_cu, char name[256]) {
+    if (cus) *cus = d->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = d->prop.clockRate;
+    if (lds_per_cu) *lds_per_cu = d->prop.maxSharedMemoryPerMultiProcessor;
+    if (name) {
+        strncpy(name, d->prop.name, 255);
+        name[255] = 0;
+    }
+    return true;
+}
+
+bool synchronize(Device* d, std::string& err) {
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    return true;
+}
+
+// LDS budget per workgroup that still leaves two workgroups per CU.
+constexpr uint32_t kLdsSceneLimit = 64u * 1024u;
+
+static uint32_t stack_bytes(const SceneLayout& L) { return std::max(1u, L.max_depth) * BLOCK * 4u; }
+
+bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err) {
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    size_t bytes = ((size_t)layout.total_bytes + 15u) & ~(size_t)15u;
+    if (bytes > d->scene_cap) {
+        hipFree(d->scene);
+        d->scene = nullptr;
+        d->scene_cap = 0;
+        PT_HIP(hipMalloc(&d->scene, bytes));
+        d->scene_cap = bytes;
+    }
+    PT_HIP(hipMemset(d->scene, 0, bytes));
+    PT_HIP(hipMemcpy(d->scene, blob, layout.total_bytes, hipMemcpyHostToDevice));
+    d->layout = layout;
+    d->have_scene = true;
+    d->scene_in_lds = bytes + stack_bytes(layout) <= kLdsSceneLimit;
+    if (stack_bytes(layout) > 64u * 1024u) {
+        err = "scene: BVH too deep for the traversal stack";
+        d->have_scene = false;
+        return false;
+    }
+    return true;
+}
+
+bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
+    if (width == 0 || height == 0 || width > 65535u || height > 65535u) {
+        err = "image size must be in [1, 65535] per side";
+        return false;
+    }
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    uint32_t n_pix = width * height;
+    hipFree(d->accum);
+    hipFree(d->pixel_hash);
+    d->accum = nullptr;
+    d->pixel_hash = nullptr;
+    PT_HIP(hipMalloc(&d->accum, (size_t)n_pix * sizeof(f4)));
+    PT_HIP(hipMalloc(&d->pixel_hash, (size_t)n_pix * sizeof(uint32_t)));
+    d->width = width, d->height = height, d->n_pix = n_pix;
+    hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
+                       height);
+    PT_HIP(hipGetLastError());
+    return clear(d, err);
+}
+
+bool clear(Device* d, std::string& err) {
+    if (!d->accum) {
+        err = "no accumulator (resize first)";
+        return false;
+    }
+    PT_HIP(hipSetDevice(d->id));
+    f4 v{0.0f, 0.0f, 0.0f, 1.0f};  // LoadOp::Clear(0,0,0,1), reference mod.rs:182-187
+    hipLaunchKernelGGL(pt_fill_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum, d->n_pix,
+                       v);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipMemsetAsync(d->counters, 0, 256, d->stream));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    return true;
+}
+
+bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err) {
+    if (n_floats != (size_t)d->n_pix * 4) {
+        err = "read_accum: n_floats must be 4 * width * height";
+        return false;
+    }
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    PT_HIP(hipMemcpy(rgba, d->accum, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return true;
+}
+
+bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err) {
+    if (n_floats != (size_t)d->n_pix * 4) {
+        err = "write_accum: n_floats must be 4 * width * height";
+        return false;
+    }
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    PT_HIP(hipMemcpy(d->accum, rgba, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    return true;
+}
+
+template <bool LDS_SCENE, bool COUNT>
+static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, std::string& err) {
+    auto kern = pt_render_kernel<LDS_SCENE, COUNT>;
+    if (lds_bytes > 48u * 1024u)
+        PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_bytes));
+    int per_cu = 0;
+    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds_bytes));
+    if (per_cu < 1) per_cu = 1;
+    uint32_t grid = (uint32_t)d->prop.multiProcessorCount * (uint32_t)per_cu;
+    // never launch more waves than there are 64-path units
+    uint32_t max_blocks = (P.total_units + 3u) / 4u;
+    grid = std::max(1u, std::min(grid, max_blocks));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, d->stream, P);
+    PT_HIP(hipGetLastError());
+    return true;
+}
+
+static hipEvent_t get_event(Device* d, size_t i) {
+    while (d->events.size() <= i) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        d->events.push_back(e);
+    }
+    return d->events[i];
+}
+
+bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+            RenderStats& stats, std::string& err) {
+    if (!d->have_scene) {
+        err = "render: no scene";
+        return false;
+    }
+    if (!d->accum) {
+        err = "render: no accumulator";
+        return false;
+    }
+    if (cfg.samples < 1) {
+        err = "render: settings.samples must be >= 1";
+        return false;
+    }
+    if (n_frames == 0) return true;
+    PT_HIP(hipSetDevice(d->id));
+
+    const uint32_t tiles_x = (d->width + 7) / 8, tiles_y = (d->height + 7) / 8;
+    const uint32_t tiles = tiles_x * tiles_y;
+    // frames per launch: bounded by a 2 GiB frame buffer and by 32-bit path ids
+    uint32_t batch = cfg.max_batch;
+    if (batch == 0) {
+        size_t by_mem = ((size_t)2 << 30) / ((size_t)d->n_pix * sizeof(f4));
+        batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_mem, 64));
+    }
+    batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
+    batch = std::min(batch, n_frames);
+    size_t need = (size_t)batch * d->n_pix;
+    if (need > d->frame_cap) {
+        PT_HIP(hipStreamSynchronize(d->stream));
+        hipFree(d->frame_buf);
+        d->frame_buf = nullptr;
+        d->frame_cap = 0;
+        PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
+        d->frame_cap = need;
+    }
+    if (n_frames > d->seeds_cap) {
+        PT_HIP(hipStreamSynchronize(d->stream));
+        hipFree(d->seeds);
+        d->seeds = nullptr;
+        d->seeds_cap = 0;
+        PT_HIP(hipMalloc(&d->seeds, (size_t)n_frames * 4));
+        d->seeds_cap = n_frames;
+    }
+    PT_HIP(hipStreamSynchronize(d->stream));
+    PT_HIP(hipMemcpy(d->seeds, seeds, (size_t)n_frames * 4, hipMemcpyHostToDevice));
+
+    RenderParams P;
+    memset(&P, 0, sizeof P);
+    P.scene = d->scene;
+    P.L = d->layout;
+    P.cam = cam;
+    P.width = d->width, P.height = d->height, P.tiles_x = tiles_x, P.tiles_per_frame = tiles, P.n_pix = d->n_pix;
+    P.samples = cfg.samples, P.depth = cfg.depth;
+    P.pixel_hash = d->pixel_hash;
+    P.frame_out = d->frame_buf;
+    P.work_counter = d->work_counter;
+    P.counters = d->counters;
+    P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
+    const bool in_lds = d->scene_in_lds;
+    P.scene_lds_bytes = in_lds ? (uint32_t)(((size_t)d->layout.total_bytes + 15u) & ~(size_t)15u) : 0u;
+    const uint32_t lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout);
+
+    size_t ev = 0;
+    uint32_t launches = 0;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
+        const uint32_t nb = std::min(batch, n_frames - f0);
+        P.total_units = nb * tiles;
+        P.seeds = d->seeds + f0;
+        PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
+        PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
+        bool ok;
+        if (in_lds) ok = cfg.count ? launch_render<true, true>(d, P, lds_bytes, err) : launch_render<true, false>(d, P, lds_bytes, err);
+        else ok = cfg.count ? launch_render<false, true>(d, P, lds_bytes, err) : launch_render<false, false>(d, P, lds_bytes, err);
+        if (!ok) return false;
+        PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
+        hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum,
+                           d->frame_buf, d->n_pix, nb, d->counters + 8);
+        PT_HIP(hipGetLastError());
+        PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
+        launches++;
+    }
+    PT_HIP(hipStreamSynchronize(d->stream));
+    for (size_t i = 0; i + 3 <= ev; i += 3) {
+        float a = 0.0f, b = 0.0f;
+        PT_HIP(hipEventElapsedTime(&a, d->events[i], d->events[i + 1]));
+        PT_HIP(hipEventElapsedTime(&b, d->events[i + 1], d->events[i + 2]));
+        stats.render_ms += a;
+        stats.resolve_ms += b;
+    }
+    unsigned long long host_counters[9];
+    PT_HIP(hipMemcpy(host_counters, d->counters, sizeof host_counters, hipMemcpyDeviceToHost));
+    stats.nodes = host_counters[0];
+    stats.tests = host_counters[1];
+    stats.accepted = host_counters[2];
+    for (int k = 0; k < 5; k++) stats.bounces[k] = host_counters[3 + k];
+    stats.rays = host_counters[8];
+    stats.paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * n_frames;
+    stats.launches += launches;
+    return true;
+}
+
+}  // namespace gpu
+}  // namespace pt

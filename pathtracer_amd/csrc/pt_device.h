@@ -1,0 +1,391 @@
+// Per-lane arithmetic of the path tracer: RNG, pixel hash, camera ray, closest hit over the
+// internal BVH, material scatter, sky.  Included by the HIP kernels; every function is also
+// compilable for the host so the per-lane logic can be exercised without a GPU.
+//
+// Arithmetic contract for everything that reaches a pixel value (follows the reference shader
+// src/renderer/compute.wgsl in source order; what WGSL leaves to the driver is fixed here):
+//   * one IEEE binary32 operation per + - * / sqrt, no FMA contraction (-ffp-contract=off),
+//   * dot(a,b) = (a.x*b.x + a.y*b.y) + a.z*b.z,  normalize(v) = v * (1/sqrt(dot(v,v))),
+//   * reflect(d,n) = d - (2*dot(n,d))*n,  pow(x,5) = (x*x)*(x*x)*x,  sin = det_sin,
+//   * u32(f) saturates, a zero pixel seed becomes 0x9E3779B9.
+// The box tests of the traversal do NOT reach a pixel value (they only cull, conservatively: all
+// boxes carry the reference's 0.01 padding), so they are free to use FMA and a different tree.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#include "pt_types.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PT_FN __host__ __device__ __forceinline__
+#else
+#define PT_FN inline
+#endif
+
+namespace pt {
+
+struct V3 {
+    float x, y, z;
+};
+PT_FN V3 mk(float x, float y, float z) {
+    V3 v;
+    v.x = x, v.y = y, v.z = z;
+    return v;
+}
+PT_FN V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_FN V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_FN V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+PT_FN V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+PT_FN V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+PT_FN V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_FN float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+PT_FN V3 normalize3(V3 v) {
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    return v * inv;
+}
+PT_FN V3 reflect3(V3 d, V3 n) {
+    float k = 2.0f * dot3(n, d);
+    return d - k * n;
+}
+
+// ---- random: compute.wgsl:1-35 ---------------------------------------------------------------
+PT_FN uint32_t randu(uint32_t& s) {
+    uint32_t r = s;
+    r ^= r << 13;
+    r ^= r >> 17;
+    r ^= r << 5;
+    s = r;
+    return r;
+}
+// f32(randu) / f32(0xffffffffu): the divisor rounds to 2^32, so this is an exact scaling.
+PT_FN float randf(uint32_t& s) { return (float)randu(s) * 2.3283064365386963e-10f; }
+PT_FN V3 rand_in_sphere(uint32_t& s) {
+    for (;;) {
+        float x = 2.0f * randf(s) - 1.0f;
+        float y = 2.0f * randf(s) - 1.0f;
+        float z = 2.0f * randf(s) - 1.0f;
+        float l2 = x * x + y * y + z * z;
+        if (l2 < 1.0f) return mk(x, y, z);
+    }
+}
+// Deterministic sine: nearest multiple of pi/2 removed in three Cody-Waite steps, then the
+// Cephes single-precision minimax polynomials; plain IEEE ops only.
+PT_FN float det_sin(float x) {
+    float kf = x * 0.63661975f;
+    float kr = kf + (kf < 0.0f ? -0.5f : 0.5f);
+    int32_t k = (int32_t)kr;
+    float fk = (float)k;
+    float r = x - fk * 1.5703125f;
+    r = r - fk * 4.837512969970703125e-4f;
+    r = r - fk * 7.54978995489188216e-8f;
+    float z = r * r;
+    float s = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    float c = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z -
+              0.5f * z + 1.0f;
+    int q = k & 3;
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+PT_FN uint32_t sat_u32(float f) {
+    if (!(f > 0.0f)) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+// compute.wgsl:2-4, 392-400
+PT_FN uint32_t pixel_hash(uint32_t px, uint32_t py, uint32_t w, uint32_t h) {
+    float ux = ((float)px + 0.5f) / (float)w;
+    float uy = ((float)py + 0.5f) / (float)h;
+    float nx = ux * 2.0f - 1.0f;
+    float ny = -(uy * 2.0f - 1.0f);
+    float d = nx * 12.9898f + ny * 78.233f;
+    float v = det_sin(d) * 43758.5453f;
+    float fr = v - floorf(v);
+    return sat_u32(fr * 4294967296.0f);
+}
+PT_FN uint32_t pixel_seed(uint32_t frame_seed, uint32_t hash) {
+    uint32_t s = frame_seed + hash;
+    return s ? s : 0x9E3779B9u;
+}
+
+// ---- camera: compute.wgsl:63-68, 405-413 -----------------------------------------------------
+struct CameraRegs {
+    V3 pos, horizontal, vertical, center;
+};
+PT_FN CameraRegs load_camera(const Camera64& c) {
+    CameraRegs r;
+    r.pos = mk(c.pos[0], c.pos[1], c.pos[2]);
+    r.horizontal = mk(c.horizontal[0], c.horizontal[1], c.horizontal[2]);
+    r.vertical = mk(c.vertical[0], c.vertical[1], c.vertical[2]);
+    r.center = mk(c.center[0], c.center[1], c.center[2]);
+    return r;
+}
+// Draws the two jitter numbers (x first) and returns the primary direction.
+PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, float fh, uint32_t& rng) {
+    float rx = randf(rng);
+    float ry = randf(rng);
+    float ux = ((float)px + rx) / fw;
+    float uy = ((float)py + ry) / fh;
+    float nx = ux * 2.0f - 1.0f;
+    float ny = -(uy * 2.0f - 1.0f);
+    return normalize3(cam.center + cam.horizontal * nx + cam.vertical * ny - cam.pos);
+}
+
+// ---- memory views ----------------------------------------------------------------------------
+// The scene blob is read through a view so the same code serves a blob staged in LDS, a blob in
+// global memory, and a host buffer.
+struct PtrMem {
+    const char* base;
+    template <class T>
+    PT_FN T load(uint32_t byte_off) const {
+        return *reinterpret_cast<const T*>(base + byte_off);
+    }
+};
+
+struct Hit {
+    float t;
+    int32_t idx;  // leaf-order sphere index, -1 = none
+    bool back;
+};
+
+struct Counters {
+    uint32_t nodes, tests, accepted;
+};
+
+constexpr int32_t TRAVERSAL_DONE = INT32_MIN;
+
+// Slab test of one child box against the ray (inv = 1/dir, ood = org/dir), clipped to [0, tcap].
+PT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 ood, float tcap,
+                float& tnear) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_FMA(a, b, c) __builtin_fmaf(a, b, c)
+#else
+#define PT_FMA(a, b, c) fmaf(a, b, c)
+#endif
+    float x0 = PT_FMA(lox, inv.x, -ood.x), x1 = PT_FMA(hix, inv.x, -ood.x);
+    float y0 = PT_FMA(loy, inv.y, -ood.y), y1 = PT_FMA(hiy, inv.y, -ood.y);
+    float z0 = PT_FMA(loz, inv.z, -ood.z), z1 = PT_FMA(hiz, inv.z, -ood.z);
+#undef PT_FMA
+    float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
+    float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcap));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// Closest hit (compute.wgsl:208-268 + 115-150) over the internal BVH.  The result is the sphere
+// with the smallest accepted root; on an exact tie the sphere that comes later in the reference's
+// own flattened order wins (its walk replaces the record when t == closest.t), which is what the
+// tie rank in `info` encodes.  Traversal order and tree shape therefore do not affect the result.
+template <class Mem, class Stack, bool COUNT>
+PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
+                       Counters& cnt) {
+    // Reciprocal direction for the slab tests only; tiny components are clamped so no inf/NaN
+    // enters the box arithmetic (the clamp never reaches a pixel value).
+    V3 dc = d;
+    if (fabsf(dc.x) < 1e-20f) dc.x = copysignf(1e-20f, dc.x);
+    if (fabsf(dc.y) < 1e-20f) dc.y = copysignf(1e-20f, dc.y);
+    if (fabsf(dc.z) < 1e-20f) dc.z = copysignf(1e-20f, dc.z);
+    V3 inv = mk(1.0f / dc.x, 1.0f / dc.y, 1.0f / dc.z);
+    V3 ood = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+
+    float best_t = INFINITY;
+    int32_t best_idx = -1;
+    bool best_back = false;
+    uint32_t best_rank = 0;
+
+    int32_t cur = 0;  // a scene has >= 2 spheres, so node 0 is interior
+    int sp = 0;
+    for (;;) {
+        while (cur >= 0) {
+            uint32_t off = L.off_nodes + (uint32_t)cur * 64u;
+            f4 q0 = mem.template load<f4>(off);
+            f4 q1 = mem.template load<f4>(off + 16);
+            f4 q2 = mem.template load<f4>(off + 32);
+            u2 ch = mem.template load<u2>(off + 48);
+            if (COUNT) cnt.nodes++;
+            float t0, t1;
+            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, ood, best_t, t0);
+            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, ood, best_t, t1);
+            int32_t c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
+            if (h0 && h1) {
+                bool swap = t1 < t0;
+                int32_t nearc = swap ? c1 : c0;
+                int32_t farc = swap ? c0 : c1;
+                stack.push(sp, farc);
+                sp++;
+                cur = nearc;
+            } else if (h0) {
+                cur = c0;
+            } else if (h1) {
+                cur = c1;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack.pop(sp);
+            } else {
+                cur = TRAVERSAL_DONE;
+            }
+        }
+        if (cur == TRAVERSAL_DONE) break;
+        {
+            uint32_t ref = ~(uint32_t)cur;
+            uint32_t first = ref & LEAF_FIRST_MASK;
+            uint32_t count = (ref >> LEAF_COUNT_SHIFT) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                uint32_t si = first + k;
+                f4 s = mem.template load<f4>(L.off_spheres + si * 16u);
+                if (COUNT) cnt.tests++;
+                // compute.wgsl:116-135
+                V3 oc = o - mk(s.x, s.y, s.z);
+                float half_b = dot3(oc, d);
+                float c = dot3(oc, oc) - (s.w * s.w);
+                float disc = half_b * half_b - c;
+                if (!(disc < 0.0f)) {
+                    float sq = sqrtf(disc);
+                    float t = -half_b - sq;
+                    bool back = false;
+                    if (t < 0.0f) {
+                        t = -half_b + sq;
+                        back = true;
+                    }
+                    if (!(t < 0.0f)) {
+                        bool take = t < best_t;
+                        if (t == best_t && best_idx >= 0) {
+                            uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
+                            take = rank > best_rank;
+                        }
+                        if (take) {
+                            if (COUNT) cnt.accepted++;
+                            best_t = t;
+                            best_idx = (int32_t)si;
+                            best_back = back;
+                            best_rank = mem.template load<u2>(L.off_info + si * 8u).y;
+                        }
+                    }
+                }
+            }
+        }
+        if (sp > 0) {
+            sp--;
+            cur = stack.pop(sp);
+        } else {
+            break;
+        }
+    }
+    hit.t = best_t;
+    hit.idx = best_idx;
+    hit.back = best_back;
+}
+
+// ---- materials: compute.wgsl:197-207, 269-368 ---------------------------------------------------
+PT_FN V3 refract3(V3 i, V3 n, float eta) {
+    float cos_theta = fminf(dot3(-i, n), 1.0f);
+    V3 perp = eta * (i + cos_theta * n);
+    V3 par = -sqrtf(fabsf(1.0f - dot3(perp, perp))) * n;
+    return perp + par;
+}
+PT_FN float reflectance(float cosine, float ref_idx) {
+    float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
+    r0 = r0 * r0;
+    float x = 1.0f - cosine;
+    float x2 = x * x;
+    return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+PT_FN V3 sky(float dir_y) {
+    float t = (dir_y + 1.0f) / 2.0f;
+    return (1.0f - t) * mk(1.0f, 1.0f, 1.0f) + t * mk(0.5f, 0.7f, 1.0f);
+}
+
+struct PathState {
+    V3 o, d;        // current ray
+    V3 colour;      // throughput
+    uint32_t rng;   // xorshift32 state (carries across the samples of one pixel-frame)
+    int32_t bounce; // loop index i of trace_path
+};
+
+// One iteration of trace_path's loop after the closest-hit query.  Returns true when the path
+// ends; `radiance` is then what trace_path returns.
+template <class Mem>
+PT_FN bool scatter(const Mem& mem, const SceneLayout& L, const Hit& hit, PathState& ps, int32_t depth,
+                   bool glass_always_draws, V3& radiance, uint32_t& mat_out) {
+    if (hit.idx < 0) {
+        mat_out = 4u;
+        radiance = ps.colour * sky(ps.d.y);
+        return true;
+    }
+    f4 s = mem.template load<f4>(L.off_spheres + (uint32_t)hit.idx * 16u);
+    uint32_t mbits = mem.template load<u2>(L.off_info + (uint32_t)hit.idx * 8u).x;
+    uint32_t mat_type = mbits & 7u, mat_index = mbits >> 3;
+    mat_out = mat_type;
+    // compute.wgsl:138-147: hit position and outward / flipped normal
+    V3 pos = ps.o + (ps.d * hit.t);
+    V3 norm = normalize3(pos - mk(s.x, s.y, s.z));
+    if (hit.back) norm = -norm;
+    const float dist = 0.001f;
+    V3 new_pos = pos + norm * dist;
+    if (mat_type == MAT_LIGHT) {
+        f4 m = mem.template load<f4>(L.off_lights + mat_index * 16u);
+        radiance = ps.colour * mk(m.x, m.y, m.z);
+        return true;
+    } else if (mat_type == MAT_LAMBERTIAN) {
+        if (hit.back) {
+            radiance = mk(0.0f, 0.0f, 0.0f);
+            return true;
+        }
+        f4 m = mem.template load<f4>(L.off_lambertians + mat_index * 16u);
+        V3 scattered = normalize3(norm + rand_in_sphere(ps.rng));
+        ps.o = new_pos;
+        ps.d = scattered;
+        ps.colour = ps.colour * mk(m.x, m.y, m.z);
+    } else if (mat_type == MAT_METAL) {
+        if (hit.back) {
+            radiance = mk(0.0f, 0.0f, 0.0f);
+            return true;
+        }
+        f4 m = mem.template load<f4>(L.off_metals + mat_index * 16u);
+        V3 reflected = normalize3(reflect3(ps.d, norm) + rand_in_sphere(ps.rng) * m.w);
+        ps.o = new_pos;
+        ps.d = reflected;
+        ps.colour = ps.colour * mk(m.x, m.y, m.z);
+    } else if (mat_type == MAT_GLASS) {
+        float mir = mem.template load<float>(L.off_glass + mat_index * 4u);
+        float ir = hit.back ? mir : 1.0f / mir;
+        float cos_theta = fminf(dot3(-ps.d, norm), 1.0f);
+        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+        bool cannot_refract = ir * sin_theta > 1.0f;
+        bool do_reflect = cannot_refract;
+        if (glass_always_draws || !cannot_refract) {
+            float refl = reflectance(cos_theta, ir);
+            float rnd = randf(ps.rng);
+            do_reflect = cannot_refract || refl > rnd;
+        }
+        V3 dir, np;
+        if (do_reflect) {
+            dir = reflect3(ps.d, norm);
+            np = pos + norm * dist;
+        } else {
+            dir = refract3(ps.d, norm, ir);
+            np = pos - norm * dist;
+        }
+        ps.o = np;
+        ps.d = normalize3(dir);
+    } else {  // unknown material: compute.wgsl:356-358
+        radiance = mk(0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    ps.bounce += 1;
+    if (ps.bounce > depth) {
+        // trace_path's loop condition fails with light still (0,0,0)
+        radiance = ps.colour * mk(0.0f, 0.0f, 0.0f);
+        return true;
+    }
+    return false;
+}
+
+// 8x8 pixel tiles: work unit u of a frame covers tile (u % tiles_x, u / tiles_x); slot in [0,64).
+PT_FN void tile_pixel(uint32_t unit, uint32_t slot, uint32_t tiles_x, uint32_t& px, uint32_t& py) {
+    uint32_t tx = unit % tiles_x, ty = unit / tiles_x;
+    px = tx * 8u + (slot & 7u);
+    py = ty * 8u + (slot >> 3);
+}
+
+}  // namespace pt

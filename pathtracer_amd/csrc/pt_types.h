@@ -1,0 +1,85 @@
+// Byte layouts at the boundary (exactly what the reference uploads to its storage / uniform
+// buffers) and the internal scene layout the kernels consume.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+namespace pt {
+
+// ---- reference wire formats (little-endian) ------------------------------------------------
+struct Sphere32 {  // reference src/renderer/sphere.rs:26-43
+    float pos[3];
+    float rad;
+    uint32_t mat_type;
+    uint32_t mat_index;
+    uint32_t pad[2];
+};
+struct Node48 {  // reference src/renderer/bvh.rs:20-36
+    float mn[3];
+    uint32_t pad0;
+    float mx[3];
+    uint32_t pad1;
+    uint32_t type;   // 0 = interior, index = escape; 1 = leaf, index = sphere id (bvh.rs:10-11)
+    uint32_t index;
+    uint32_t pad2[2];
+};
+struct Vec16 {  // Light{colour}, Lambertian{albedo}, Metal{albedo, roughness}: materials.rs:26-97
+    float x, y, z, w;
+};
+struct Camera64 {  // reference src/renderer/camera.rs:91-113
+    float pos[3], pad0;
+    float horizontal[3], pad1;
+    float vertical[3], pad2;
+    float center[3], pad3;
+};
+struct Globals12 {  // reference src/renderer/globals.rs:3-9
+    uint32_t seed;
+    int32_t samples;
+    int32_t depth;
+};
+static_assert(sizeof(Sphere32) == 32, "Sphere is 32 bytes on the wire");
+static_assert(sizeof(Node48) == 48, "BVHNode is 48 bytes on the wire");
+static_assert(sizeof(Vec16) == 16, "materials are 16 bytes on the wire");
+static_assert(sizeof(Camera64) == 64, "Camera is 64 bytes on the wire");
+static_assert(sizeof(Globals12) == 12, "Globals is 12 bytes on the wire");
+
+enum : uint32_t { MAT_LIGHT = 0, MAT_LAMBERTIAN = 1, MAT_METAL = 2, MAT_GLASS = 3 };  // materials.rs:3-8
+
+// ---- internal device layout ----------------------------------------------------------------
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+struct alignas(8) u2 {
+    uint32_t x, y;
+};
+
+// One interior node of the binary BVH the kernels walk: both children's boxes and both child
+// links in one 64-byte record (four 16-byte loads).
+//   q0 = c0.lo.xyz, c0.hi.x   q1 = c0.hi.yz, c1.lo.xy   q2 = c1.lo.z, c1.hi.xyz
+//   q3 = child0, child1 (int bits), 0, 0
+// child >= 0: interior node index.  child < 0: leaf, ~child = first | (count-1) << 28 over the
+// leaf-ordered sphere array.
+struct alignas(16) Node64 {
+    f4 q0, q1, q2;
+    int32_t child0, child1;
+    uint32_t pad[2];
+};
+static_assert(sizeof(Node64) == 64, "Node64");
+constexpr int LEAF_COUNT_SHIFT = 28;
+constexpr uint32_t LEAF_FIRST_MASK = (1u << LEAF_COUNT_SHIFT) - 1u;
+constexpr int MAX_LEAF_SPHERES = 4;
+
+// Scene blob: one contiguous, 16-byte aligned allocation; offsets in bytes.
+struct SceneLayout {
+    uint32_t off_nodes, n_nodes;      // Node64[]
+    uint32_t off_spheres, n_spheres;  // f4[]  (x, y, z, rad) in leaf order
+    uint32_t off_info;                // u2[]  (min(mat_type,4) | mat_index << 3, tie rank) in leaf order
+    uint32_t off_lights, n_lights;    // f4[]
+    uint32_t off_lambertians, n_lambertians;
+    uint32_t off_metals, n_metals;    // f4[]  (albedo, roughness)
+    uint32_t off_glass, n_glass;      // float[]
+    uint32_t total_bytes;
+    uint32_t max_depth;               // deepest interior-node chain; bounds the traversal stack
+};
+
+}  // namespace pt

@@ -1,0 +1,97 @@
+// Test harness only: runs the kernels' per-lane code (pathtracer_amd/csrc/pt_device.h) and the
+// library's host-side scene packing on the CPU, one path after another, so that tree building,
+// traversal and scatter logic can be compared with the oracle where no GPU exists.  It is built by
+// tests/conftest.py into tests/emul/ and is not part of libmi355pt.so.
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../pathtracer_amd/csrc/pt_device.h"
+#include "../../pathtracer_amd/csrc/scene_pack.h"
+
+using namespace pt;
+
+namespace {
+struct HostStack {
+    int32_t a[80];
+    void push(int sp, int32_t v) { a[sp] = v; }
+    int32_t pop(int sp) const { return a[sp]; }
+};
+std::string g_err;
+}  // namespace
+
+extern "C" {
+
+const char* emul_error() { return g_err.c_str(); }
+
+// counters: nodes, tests, accepted, bounce[5], rays, paths
+int emul_render(const void* spheres32, size_t n_spheres, const void* lights, size_t n_lights, const void* lamb,
+                size_t n_lamb, const void* metals, size_t n_metals, const void* glass, size_t n_glass,
+                int reference_topology, const void* ref_nodes, size_t n_ref_nodes, const void* cam64, uint32_t w,
+                uint32_t h, int32_t samples, int32_t depth, int glass_always_draws, uint32_t n_frames,
+                const uint32_t* seeds, float* accum, uint32_t x0, uint32_t x1, uint32_t y0, uint32_t y1,
+                uint64_t* counters, uint32_t* bvh_info) {
+    SceneArrays a;
+    a.spheres = (const Sphere32*)spheres32, a.n_spheres = n_spheres;
+    a.lights = (const Vec16*)lights, a.n_lights = n_lights;
+    a.lambertians = (const Vec16*)lamb, a.n_lambertians = n_lamb;
+    a.metals = (const Vec16*)metals, a.n_metals = n_metals;
+    a.glass = (const float*)glass, a.n_glass = n_glass;
+    std::vector<char> blob;
+    SceneLayout L;
+    Bvh2 bvh;
+    if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) return -1;
+    if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes;
+    PtrMem mem{blob.data()};
+    Camera64 cam64v;
+    memcpy(&cam64v, cam64, 64);
+    CameraRegs cam = load_camera(cam64v);
+    Counters cnt = {0, 0, 0};
+    uint64_t big[10] = {0};
+    const float fw = (float)w, fh = (float)h;
+    for (uint32_t y = y0; y < y1; y++)
+        for (uint32_t x = x0; x < x1; x++) {
+            float* texel = accum + 4ull * ((uint64_t)y * w + x);
+            const uint32_t hash = pixel_hash(x, y, w, h);
+            for (uint32_t f = 0; f < n_frames; f++) {
+                PathState ps;
+                ps.rng = pixel_seed(seeds[f], hash);
+                V3 final_colour = mk(0.0f, 0.0f, 0.0f);
+                for (int32_t s = 0; s < samples; s++) {
+                    ps.d = camera_dir(cam, x, y, fw, fh, ps.rng);
+                    ps.o = cam.pos;
+                    ps.colour = mk(1.0f, 1.0f, 1.0f);
+                    ps.bounce = 0;
+                    big[9]++;
+                    for (;;) {
+                        Hit hit;
+                        HostStack st;
+                        cnt = Counters{0, 0, 0};
+                        closest_hit<PtrMem, HostStack, true>(mem, L, st, ps.o, ps.d, hit, cnt);
+                        big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;
+                        V3 radiance;
+                        uint32_t mat;
+                        bool done = scatter(mem, L, hit, ps, depth, glass_always_draws != 0, radiance, mat);
+                        if (mat < 5) big[3 + mat]++;
+                        if (done) {
+                            final_colour = final_colour + radiance;
+                            break;
+                        }
+                    }
+                }
+                const float fs = (float)samples;
+                texel[0] += final_colour.x / fs;
+                texel[1] += final_colour.y / fs;
+                texel[2] += final_colour.z / fs;
+                texel[3] += 0.0f;
+            }
+        }
+    if (counters) memcpy(counters, big, sizeof big);
+    return 0;
+}
+
+uint32_t emul_pixel_hash(uint32_t px, uint32_t py, uint32_t w, uint32_t h) { return pixel_hash(px, py, w, h); }
+float emul_det_sin(float x) { return det_sin(x); }
+
+}  // extern "C"
