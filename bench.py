@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X: scene1.ron at 1920x1080, 1 sample per frame, depth 50.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the path kernel over one batch of frames (default 64 frames = 132.7 M paths per
+GPU); the default 16 steps are the 1024 frames of the headline configuration.  With N GPUs every rank
+renders its own disjoint frames (weak scaling), and the accumulators are sum-reduced to rank 0 over
+RCCL inside the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak), packed FMA counted as 2x2
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_per_launch(st):
+    """Algorithmic FLOPs of the traversal actually run, from the counting kernels: 24 per box test
+    (two per fetched node), 17 per sphere test, 18 per accepted hit, and per bounce 60 (lambertian /
+    metal incl. the mean 1.91 rejection tries), 45 (glass), 8 (sky), 0 (light)."""
+    b = st["bounces"]
+    return (st["nodes"] * 2 * 24 + st["tests"] * 17 + st["accepted"] * 18 +
+            (b["lambertian"] + b["metal"]) * 60 + b["glass"] * 45 + b["sky"] * 8)
+
+
+def bytes_per_launch(st):
+    """Algorithmic scene bytes fetched: 64 per interior node record, 16 per sphere record, 24 per
+    bounce (sphere + material info + material record)."""
+    hits = sum(st["bounces"][k] for k in ("light", "lambertian", "metal", "glass"))
+    return st["nodes"] * 64 + st["tests"] * 16 + hits * 40
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--scene", default=os.path.join(ROOT, "fixtures", "scene1.ron"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rmse", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch  # first, so the process uses one HIP runtime for torch and the library
+    import torch.distributed as dist
+    import numpy as np
+
+    import pathtracer_amd as pa
+    from pathtracer_amd import parallel
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, F = args.width, args.height, args.frames_per_step
+    scene = pa.load_ron_scene(args.scene)
+    settings = pa.Settings(1, 50)
+    base_seed = 0x00C0FFEE
+    r = pa.Renderer(scene, settings, W, H, device=local_rank, base_seed=base_seed)
+    acc_t = parallel.accum_tensor(r, local_rank) if world > 1 else None
+
+    def step_seeds(step):
+        # global frame index: steps interleave ranks so every rank's frames are disjoint
+        first = (step * world + rank) * F
+        return parallel.seeds_for(base_seed, range(first, first + F), pa.frame_seed)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for s in range(args.warmup):
+        r.render(seeds=step_seeds(args.steps + s))
+    if world > 1 and args.warmup:
+        warm = torch.zeros_like(acc_t)
+        dist.reduce(warm, dst=0)  # communicator set-up outside the timed region
+    r.clear()
+    sync()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        r.render(seeds=step_seeds(s))
+    if world > 1:
+        parallel.reduce_accum(acc_t, world, dst=0)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    st = r.stats()
+    counts = torch.tensor([st["paths"], st["rays"]], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    paths_all, rays_all = float(counts[0].item()), float(counts[1].item())
+
+    if rank == 0:
+        kernel_ms = st["render_ms"] / max(1, st["launches"])   # HIP events on the render stream
+        out = {
+            "metric": "Mrays/s", "value": rays_all / dt / 1e6, "unit": "Mrays/s",
+            "mpaths_per_s": paths_all / dt / 1e6,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, {F} frames/step x {args.steps} steps "
+                                   f"per GPU, 1 spp/frame, depth 50 (BASELINE configs[1])",
+                       "frames_per_gpu": F * args.steps, "paths_per_step_per_gpu": W * H * F,
+                       "parallelism": f"frame-partitioned x{world}, one RCCL sum-reduce" if world > 1 else "1 GPU",
+                       "bvh": "binned SAH, 64-B two-child nodes", "scene_in_lds": bool(st["scene_in_lds"])},
+            "rays_per_path": rays_all / paths_all,
+            "kernel_ms_per_launch": kernel_ms,
+            "resolve_ms_per_launch": st["resolve_ms"] / max(1, st["launches"]),
+        }
+        # ---- roofline of the dominant kernel (pt_render_kernel), per launch
+        with pa.Renderer(scene, settings, W, H, device=local_rank, base_seed=base_seed, flags=pa.FLAG_COUNT) as rc:
+            rc.render(seeds=step_seeds(0))
+            cs = rc.stats()
+        fl = flops_per_launch(cs)
+        by = bytes_per_launch(cs)
+        ach = fl / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+            "kernel": "pt_render_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
+            "nodes_per_ray": cs["nodes"] / cs["rays"], "sphere_tests_per_ray": cs["tests"] / cs["rays"],
+            "note": "scene (22 KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
+                    "vector FP32 figure (equal to the FP32 MFMA peak)",
+            "scene_fetch": {"bytes_per_ray": by / cs["rays"], "achieved_GBps": by / (kernel_ms * 1e-3) / 1e9,
+                            "served_from": "LDS" if cs["scene_in_lds"] else "L2/HBM", "hbm_peak_GBps": PEAK_HBM_GBS},
+        }
+        # ---- converged-image parity against the reference's own render (outside the timed region)
+        if not args.no_rmse and os.path.basename(args.scene) == "scene1.ron":
+            try:
+                from PIL import Image
+                ref = np.asarray(Image.open(os.path.join(ROOT, "fixtures", "mdimg.png")).convert("RGB")).astype(np.float64)
+                with pa.Renderer(scene, settings, 1280, 720, device=local_rank, base_seed=base_seed) as ri:
+                    ri.render(1000)
+                    img = ri.to_rgb8().astype(np.float64)
+                rmse = float(np.sqrt(np.mean((img - ref) ** 2)))
+                out["rmse_vs_reference_png_8bit"] = rmse
+                out["psnr_vs_reference_png_db"] = float(20 * np.log10(255.0 / rmse))
+            except Exception as e:  # the image check must not hide the measurement
+                out["rmse_vs_reference_png_8bit"] = f"unavailable: {e}"
+        # ---- CPU baseline: the oracle (restatement of the reference algorithm) on a bounded sample
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import orc
+            osc = orc.Scene.from_ron(args.scene)
+            threads = min(16, os.cpu_count() or 1)
+            n_cpu_frames = 8
+            seeds = step_seeds(0)[:n_cpu_frames]
+            t1 = time.perf_counter()
+            _, ost = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=threads)
+            cdt = time.perf_counter() - t1
+            out["cpu_baseline"] = {
+                "value": ost["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                "mpaths_per_s": ost["paths"] / cdt / 1e6,
+                "sample": f"{n_cpu_frames} of the step-0 frames of the same workload ({W}x{H}, depth 50), CPU "
+                          f"restatement of the reference algorithm (reference BVH topology, 48-B nodes), "
+                          f"{cdt:.1f} s wall",
+            }
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,7 @@ import subprocess
 
 import numpy as np
 
-from . import ronlite
+from . import ronlite  # noqa: F401 (re-exported as orc.ronlite)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libpt_oracle.so")

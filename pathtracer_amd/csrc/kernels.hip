@@ -313,24 +313,24 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
         err = "hipMalloc failed";
         return false;
     }
-    hipMemset(d->counters, 0, 256);
+    (void)hipMemset(d->counters, 0, 256);
     *out = d;
     return true;
 }
 
 void destroy(Device* d) {
     if (!d) return;
-    hipSetDevice(d->id);
-    if (d->stream) hipStreamSynchronize(d->stream);
-    for (hipEvent_t e : d->events) hipEventDestroy(e);
-    hipFree(d->scene);
-    hipFree(d->accum);
-    hipFree(d->pixel_hash);
-    hipFree(d->frame_buf);
-    hipFree(d->seeds);
-    hipFree(d->work_counter);
-    hipFree(d->counters);
-    if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
+    (void)hipSetDevice(d->id);
+    if (d->stream) (void)hipStreamSynchronize(d->stream);
+    for (hipEvent_t e : d->events) (void)hipEventDestroy(e);
+    (void)hipFree(d->scene);
+    (void)hipFree(d->accum);
+    (void)hipFree(d->pixel_hash);
+    (void)hipFree(d->frame_buf);
+    (void)hipFree(d->seeds);
+    (void)hipFree(d->work_counter);
+    (void)hipFree(d->counters);
+    if (d->own_stream && d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
 
@@ -366,7 +366,7 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
     PT_HIP(hipStreamSynchronize(d->stream));
     size_t bytes = ((size_t)layout.total_bytes + 15u) & ~(size_t)15u;
     if (bytes > d->scene_cap) {
-        hipFree(d->scene);
+        (void)hipFree(d->scene);
         d->scene = nullptr;
         d->scene_cap = 0;
         PT_HIP(hipMalloc(&d->scene, bytes));
@@ -393,8 +393,8 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     PT_HIP(hipSetDevice(d->id));
     PT_HIP(hipStreamSynchronize(d->stream));
     uint32_t n_pix = width * height;
-    hipFree(d->accum);
-    hipFree(d->pixel_hash);
+    (void)hipFree(d->accum);
+    (void)hipFree(d->pixel_hash);
     d->accum = nullptr;
     d->pixel_hash = nullptr;
     PT_HIP(hipMalloc(&d->accum, (size_t)n_pix * sizeof(f4)));
@@ -464,7 +464,7 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
 static hipEvent_t get_event(Device* d, size_t i) {
     while (d->events.size() <= i) {
         hipEvent_t e;
-        hipEventCreate(&e);
+        (void)hipEventCreate(&e);
         d->events.push_back(e);
     }
     return d->events[i];
@@ -485,6 +485,13 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
         return false;
     }
     if (n_frames == 0) return true;
+    if (cfg.depth < 0) {
+        // trace_path's loop `while i <= depth` never runs (compute.wgsl:289): every path returns
+        // colour * light = 0, no ray is traced and no random number beyond the jitter is drawn, so
+        // the frames add exactly zero to every texel.
+        stats.paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * n_frames;
+        return true;
+    }
     PT_HIP(hipSetDevice(d->id));
 
     const uint32_t tiles_x = (d->width + 7) / 8, tiles_y = (d->height + 7) / 8;
@@ -500,7 +507,7 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     size_t need = (size_t)batch * d->n_pix;
     if (need > d->frame_cap) {
         PT_HIP(hipStreamSynchronize(d->stream));
-        hipFree(d->frame_buf);
+        (void)hipFree(d->frame_buf);
         d->frame_buf = nullptr;
         d->frame_cap = 0;
         PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
@@ -508,7 +515,7 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     }
     if (n_frames > d->seeds_cap) {
         PT_HIP(hipStreamSynchronize(d->stream));
-        hipFree(d->seeds);
+        (void)hipFree(d->seeds);
         d->seeds = nullptr;
         d->seeds_cap = 0;
         PT_HIP(hipMalloc(&d->seeds, (size_t)n_frames * 4));

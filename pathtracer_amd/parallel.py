@@ -1,0 +1,47 @@
+"""Sample-parallel rendering across the GPUs of one node: one process per GPU, frames partitioned by
+index (disjoint seed streams), one sum-reduce of the accumulators to rank 0 at the end.
+
+The reference is single-GPU; what makes this exact is that every (frame, pixel) path depends only on
+the frame's seed and the pixel (compute.wgsl:400) and frames meet only in the per-texel sum
+(compute.wgsl:419-421).  The union over ranks is the single-GPU sample set; only the order of the
+float additions across ranks differs.
+"""
+import numpy as np
+
+
+def rank_frames(n_frames, rank, world):
+    """Global frame indices rendered by `rank`: contiguous blocks, sizes differ by at most one."""
+    base, extra = divmod(int(n_frames), int(world))
+    start = rank * base + min(rank, extra)
+    return range(start, start + base + (1 if rank < extra else 0))
+
+
+class _DevicePtr:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap memory the library allocated."""
+
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def accum_tensor(renderer, device_index):
+    """The renderer's float4[H*W] accumulator as a torch tensor [H, W, 4] (no copy)."""
+    import torch
+    ptr, _stream = renderer.accum_device_ptr()
+    return torch.as_tensor(_DevicePtr(ptr, (renderer.height, renderer.width, 4)),
+                           device=torch.device("cuda", device_index))
+
+
+def reduce_accum(tensor, world, dst=0):
+    """Sum-reduce accumulators to `dst` (RCCL when the tensor is on a GPU, gloo on the CPU) and restore
+    the constant alpha of the reference's texture (every rank cleared its own to 1)."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+    if dist.get_rank() == dst if world > 1 else True:
+        tensor[..., 3] = 1.0
+    return tensor
+
+
+def seeds_for(base_seed, frames, frame_seed_fn):
+    return np.array([frame_seed_fn(base_seed, f) for f in frames], np.uint32)

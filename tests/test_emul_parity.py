@@ -1,0 +1,145 @@
+"""The kernels' per-lane code (pt_device.h) and the library's scene packing, run on the CPU by
+tests/emul, against the oracle: results must be bit-identical for every tree the library can walk."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, bits_equal, oracle_scene
+
+SEEDS = [0x00C0FFEE, 0x12345678, 7]
+
+
+def test_device_sine_and_hash_match_oracle(emul, orc):
+    L = orc.lib()
+    for x in np.linspace(-91.3, 91.3, 1001).astype(np.float32):
+        assert np.float32(emul.emul_det_sin(float(x))) == np.float32(L.orc_det_sin(float(x)))
+    for (w, h) in ((64, 36), (1920, 1080), (3840, 2160), (7, 5)):
+        for px, py in ((0, 0), (w - 1, h - 1), (w // 2, h // 2), (w // 3, h - 1)):
+            # the oracle adds the frame seed (and maps a zero sum to a constant); use seed 1
+            assert (emul.emul_pixel_hash(px, py, w, h) + 1) & 0xFFFFFFFF == L.orc_pixel_seed(1, px, py, w, h)
+
+
+@pytest.mark.parametrize("name", ["scene1", "scene2", "scene3"])
+@pytest.mark.parametrize("topo", [0, 1])
+def test_bit_identical_to_oracle(emul, orc, pa, name, topo):
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, name + ".ron"))
+    osc = oracle_scene(orc, sc)
+    W, H = 96, 54
+    cam = osc.camera(W, H)
+    ref, st = orc.render(osc, cam, W, H, SEEDS, threads=4)
+    acc, cnt, info = emul.render(sc, cam, W, H, SEEDS, ref_topo=topo)
+    assert bits_equal(ref, acc)
+    assert cnt["rays"] == st["rays"] and cnt["paths"] == st["paths"]
+    assert [cnt[k] for k in ("b_light", "b_lambertian", "b_metal", "b_glass", "b_sky")] == \
+           [st[k] for k in ("bounce_light", "bounce_lambertian", "bounce_metal", "bounce_glass", "misses")]
+
+
+@pytest.mark.parametrize("samples,depth", [(1, 0), (1, 1), (2, 3), (4, 50)])
+def test_samples_and_depth(emul, orc, pa, samples, depth):
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene3.ron"))
+    osc = oracle_scene(orc, sc)
+    W, H = 48, 27
+    cam = osc.camera(W, H)
+    ref, _ = orc.render(osc, cam, W, H, SEEDS[:2], samples=samples, depth=depth)
+    acc, _, _ = emul.render(sc, cam, W, H, SEEDS[:2], samples=samples, depth=depth)
+    assert bits_equal(ref, acc)
+
+
+@pytest.mark.parametrize("swap_mode", [1, 2])
+def test_caller_supplied_tree_with_swapped_children(emul, orc, pa, swap_mode):
+    # the reference swaps children at random (bvh.rs:107); any such tree must give the oracle's
+    # result for that same tree
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    nodes = pa.bvh_build_reference(sc.spheres, swap_mode, 99)
+    osc = oracle_scene(orc, sc, nodes=orc.bvh_build(sc.spheres, swap_mode, 99))
+    W, H = 80, 45
+    cam = osc.camera(W, H)
+    ref, _ = orc.render(osc, cam, W, H, SEEDS[:2], threads=4)
+    acc, _, _ = emul.render(sc, cam, W, H, SEEDS[:2], ref_nodes=nodes)
+    assert bits_equal(ref, acc)
+
+
+def _tie_scene(pa):
+    # two coincident spheres with different materials: every hit is an exact tie in t
+    sc = pa.Scene.default()
+    sp = np.zeros(5, pa.renderer.SPHERE_DT)
+    sp[:4] = sc.spheres
+    sp[4] = sp[0]               # duplicate of the lambertian at +x ...
+    sp[4]["mat_type"] = 0       # ... as a light
+    sc.spheres = sp
+    return sc
+
+
+@pytest.mark.parametrize("swap_mode", [0, 1])
+@pytest.mark.parametrize("topo", [0, 1])
+def test_exact_ties_resolve_like_the_reference_walk(emul, orc, pa, swap_mode, topo):
+    # compute.wgsl:129: a later leaf with t == closest.t replaces the record, so the winner is the
+    # sphere that comes last in the flattened order, whatever tree the library walks
+    sc = _tie_scene(pa)
+    W, H = 40, 30
+    if swap_mode == 0:
+        osc = oracle_scene(orc, sc)
+        cam = osc.camera(W, H)
+        acc, _, _ = emul.render(sc, cam, W, H, SEEDS, ref_topo=topo)
+    else:
+        nodes = pa.bvh_build_reference(sc.spheres, 1, 1)
+        osc = oracle_scene(orc, sc, nodes=orc.bvh_build(sc.spheres, 1, 1))
+        cam = osc.camera(W, H)
+        acc, _, _ = emul.render(sc, cam, W, H, SEEDS, ref_nodes=nodes)
+    ref, st = orc.render(osc, cam, W, H, SEEDS)
+    assert st["bounce_light"] + st["bounce_lambertian"] > 0
+    assert bits_equal(ref, acc)
+
+
+def test_unknown_material_is_black_and_short_circuit_flag(emul, orc, pa):
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene2.ron"))
+    sc.spheres = sc.spheres.copy()
+    sc.spheres["mat_type"][1] = 9  # compute.wgsl:356-358
+    osc = oracle_scene(orc, sc)
+    W, H = 48, 27
+    cam = osc.camera(W, H)
+    ref, _ = orc.render(osc, cam, W, H, SEEDS[:1])
+    acc, _, _ = emul.render(sc, cam, W, H, SEEDS[:1])
+    assert bits_equal(ref, acc)
+    # glass short-circuit variant (compute.wgsl:344 read literally).  Total internal reflection needs
+    # overlapping glass (a lone sphere always lets a ray out), which scene1 has in a few places.
+    sc1 = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    o1 = oracle_scene(orc, sc1)
+    W, H = 96, 54
+    cam1 = o1.camera(W, H)
+    seeds = [1, 2, 3, 4]
+    orc.lib().orc_set_glass_always_draws(0)
+    try:
+        ref1, _ = orc.render(o1, cam1, W, H, seeds, threads=4)
+    finally:
+        orc.lib().orc_set_glass_always_draws(1)
+    acc1, _, _ = emul.render(sc1, cam1, W, H, seeds, glass=0)
+    assert bits_equal(ref1, acc1)
+    always, _ = orc.render(o1, cam1, W, H, seeds, threads=4)
+    assert not bits_equal(always, ref1)
+
+
+def test_synthetic_plane_scene_crop(emul, orc, pa):
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(5000)
+    osc = oracle_scene(orc, sc)
+    W, H = 320, 180
+    cam = osc.camera(W, H)
+    crop = (100, 164, 60, 96)
+    ref, st = orc.render(osc, cam, W, H, SEEDS[:2], crop=crop, threads=4)
+    acc, cnt, info = emul.render(sc, cam, W, H, SEEDS[:2], crop=crop)
+    assert bits_equal(ref, acc)
+    # the SAH tree visits far fewer nodes than the reference's z-only split
+    assert cnt["nodes"] * 2 < st["interior_visits"]
+
+
+def test_sah_tree_is_shallower_in_work_than_reference_tree(emul, orc, pa):
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    osc = oracle_scene(orc, sc)
+    W, H = 64, 36
+    cam = osc.camera(W, H)
+    _, c_sah, i_sah = emul.render(sc, cam, W, H, SEEDS[:1], ref_topo=0)
+    _, c_ref, i_ref = emul.render(sc, cam, W, H, SEEDS[:1], ref_topo=1)
+    assert i_ref[0] == 319 and i_ref[1] == 9          # 2n-1 nodes -> n-1 interior, balanced depth
+    assert c_sah["nodes"] < c_ref["nodes"]

@@ -1,0 +1,238 @@
+"""Known-answer tests of the CPU oracle, derived by reading the reference (no execution needed)."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, GOLDEN, bits_equal
+
+
+def f3(*a):
+    return (C.c_float * 3)(*a)
+
+
+def test_xorshift32_sequence(orc):
+    # compute.wgsl:5-12: r ^= r << 13; r ^= r >> 17; r ^= r << 5 (u32 wrapping)
+    L = orc.lib()
+    for seed in (1, 2, 0x00C0FFEE, 0xFFFFFFFF, 0x80000000):
+        st = C.c_uint32(seed)
+        r = seed
+        for _ in range(64):
+            r ^= (r << 13) & 0xFFFFFFFF
+            r ^= r >> 17
+            r ^= (r << 5) & 0xFFFFFFFF
+            assert L.orc_randu(C.byref(st)) == r
+            assert st.value == r
+
+
+def test_randf_is_exact_scaling(orc):
+    # compute.wgsl:13-15: f32(r) / f32(0xffffffff); the divisor rounds to 2^32
+    L = orc.lib()
+    st = C.c_uint32(12345)
+    ref = C.c_uint32(12345)
+    for _ in range(256):
+        r = L.orc_randu(C.byref(ref))
+        v = L.orc_randf(C.byref(st))
+        assert np.float32(v) == np.float32(np.float32(r) * np.float32(2.0 ** -32))
+        assert 0.0 <= v <= 1.0
+
+
+def test_rand_in_sphere_order_and_rejection(orc):
+    # compute.wgsl:19-30: x, y, z in that order; reject until x^2+y^2+z^2 < 1
+    L = orc.lib()
+    for seed in (7, 99, 0xABCDEF):
+        st = C.c_uint32(seed)
+        ref = C.c_uint32(seed)
+        out = f3(0, 0, 0)
+        L.orc_rand_in_sphere(C.byref(st), out)
+        while True:
+            v = [np.float32(2.0) * np.float32(L.orc_randf(C.byref(ref))) - np.float32(1.0) for _ in range(3)]
+            if v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0:
+                break
+        assert [np.float32(x) for x in out] == v
+        assert st.value == ref.value
+
+
+def test_miss_sky(orc):
+    # compute.wgsl:269-276
+    L = orc.lib()
+    out = f3(0, 0, 0)
+    for dy, want in ((1.0, (0.5, 0.7, 1.0)), (-1.0, (1.0, 1.0, 1.0)), (0.0, (0.75, 0.85, 1.0))):
+        L.orc_miss(dy, out)
+        assert np.allclose(list(out), want, atol=1e-7)
+
+
+def test_ray_sphere_known_answers(orc):
+    # compute.wgsl:115-150
+    sph = np.zeros(1, orc.ronlite.SPHERE_DT)
+    sph[0]["rad"] = 1.0
+    rec = (C.c_float * 8)()
+    L = orc.lib()
+    inf = float("inf")
+    assert L.orc_ray_sphere(sph.ctypes.data, f3(0, 0, -3), f3(0, 0, 1), 0.0, inf, rec) == 1
+    assert rec[0] == 2.0 and list(rec[4:7]) == [0.0, 0.0, -1.0] and rec[7] == 0.0
+    # from the centre: first root -1 rejected, second root +1, back face, normal flipped
+    assert L.orc_ray_sphere(sph.ctypes.data, f3(0, 0, 0), f3(0, 0, 1), 0.0, inf, rec) == 1
+    assert rec[0] == 1.0 and rec[7] == 1.0 and list(rec[4:7]) == [-0.0, -0.0, -1.0]
+    # behind the ray / beyond t_max
+    assert L.orc_ray_sphere(sph.ctypes.data, f3(0, 0, 3), f3(0, 0, 1), 0.0, inf, rec) == 0
+    assert L.orc_ray_sphere(sph.ctypes.data, f3(0, 0, -3), f3(0, 0, 1), 0.0, 1.5, rec) == 0
+    # t == t_max is accepted (the reject test is t > t_max)
+    assert L.orc_ray_sphere(sph.ctypes.data, f3(0, 0, -3), f3(0, 0, 1), 0.0, 2.0, rec) == 1
+
+
+def test_reflectance(orc):
+    # compute.wgsl:203-207
+    L = orc.lib()
+    assert abs(L.orc_reflectance(1.0, 1.5) - 0.04) < 1e-7
+    assert L.orc_reflectance(0.0, 1.5) == 1.0
+    assert L.orc_reflectance(0.0, 2.4) == 1.0
+
+
+def test_vector3_unit_tests_of_the_reference(orc):
+    # src/renderer/vector3.rs:130-187, the reference's only tests
+    L = orc.lib()
+    out = f3(0, 0, 0)
+    z = f3(0, 0, 0)
+    L.orc_vector3(0, f3(2, 0, 0), z, out)
+    assert out[0] == 2.0
+    L.orc_vector3(0, f3(1, 1, 1), z, out)
+    assert np.float32(out[0]) == np.sqrt(np.float32(3.0))
+    L.orc_vector3(1, f3(2, 3, 4), z, out)
+    assert out[0] == 29.0
+    L.orc_vector3(2, f3(20, 0, 0), z, out)
+    assert list(out) == [1.0, 0.0, 0.0]
+    L.orc_vector3(3, f3(1, 0, 0), f3(1, 0, 0), out)
+    assert out[0] == 1.0
+    L.orc_vector3(3, f3(1, 0, 0), f3(0, 1, 0), out)
+    assert out[0] == 0.0
+    L.orc_vector3(3, f3(1, 0, 0), f3(-1, 0, 0), out)
+    assert out[0] == -1.0
+    L.orc_vector3(4, f3(0, 0, 1), f3(0, 1, 0), out)
+    assert list(out) == [-1.0, 0.0, 0.0]
+    L.orc_vector3(4, f3(0, 1, 0), f3(0, 0, 1), out)
+    assert list(out) == [1.0, 0.0, 0.0]
+    L.orc_vector3(4, f3(2, 3, 4), f3(5, 6, 7), out)
+    assert list(out) == [-3.0, 6.0, -3.0]
+
+
+def test_byte_sizes(orc):
+    assert orc.ronlite.SPHERE_DT.itemsize == 32 and orc.ronlite.NODE_DT.itemsize == 48
+    assert orc.ronlite.VEC16_DT.itemsize == 16
+    assert orc.camera_build((0, 0, -3), 0, 0, 60, 1.5).nbytes == 64
+
+
+def test_flatten_two_spheres_and_node_count(orc):
+    # bvh.rs:60-140: 2 spheres -> [ESCAPE->3, OBJ 0, OBJ 1]; n spheres -> 2n-1 nodes
+    sp = np.zeros(2, orc.ronlite.SPHERE_DT)
+    sp["pos"][1] = (3, 0, 0)
+    sp["rad"] = 1
+    nodes = orc.bvh_build(sp)
+    assert [(int(n["type"]), int(n["index"])) for n in nodes] == [(0, 3), (1, 0), (1, 1)]
+    assert np.allclose(nodes[0]["mn"], (-1.01, -1.01, -1.01)) and np.allclose(nodes[0]["mx"], (4.01, 1.01, 1.01))
+    rng = np.random.default_rng(1)
+    for n in (3, 4, 5, 7, 8, 33, 100):
+        sp = np.zeros(n, orc.ronlite.SPHERE_DT)
+        sp["pos"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+        sp["rad"] = 0.3
+        nodes = orc.bvh_build(sp)
+        assert len(nodes) == 2 * n - 1
+        leaves = sorted(int(x["index"]) for x in nodes if x["type"] == 1)
+        assert leaves == list(range(n))
+    with pytest.raises(ValueError):
+        orc.bvh_build(np.zeros(1, orc.ronlite.SPHERE_DT))
+
+
+def test_three_spheres_pops_last_as_left_leaf(orc):
+    # bvh.rs:71-80
+    sp = np.zeros(3, orc.ronlite.SPHERE_DT)
+    sp["pos"][:, 0] = (0, 5, 10)
+    sp["rad"] = 1
+    nodes = orc.bvh_build(sp)
+    assert [(int(n["type"]), int(n["index"])) for n in nodes] == [(0, 5), (1, 2), (0, 5), (1, 0), (1, 1)]
+
+
+def test_split_is_always_on_z(orc):
+    # bvh.rs:82-96: diff comes from the sentinels, so x/y never win
+    sp = np.zeros(4, orc.ronlite.SPHERE_DT)
+    sp["pos"][:, 0] = (0, 100, 200, 300)   # widest on x
+    sp["pos"][:, 2] = (3, 1, 2, 0)          # order on z: 3, 1, 2, 0
+    sp["rad"] = 0.1
+    nodes = orc.bvh_build(sp)
+    leaves = [int(n["index"]) for n in nodes if n["type"] == 1]
+    assert leaves == [3, 1, 2, 0]
+
+
+def test_all_light_scene_has_no_randomness_in_hit_pixels(orc):
+    # every sphere emissive with colour c: a hit pixel is exactly c, everything else is sky
+    sc = orc.Scene.from_ron(os.path.join(FIXTURES, "scene3.ron"))
+    blobs = dict(sc.blobs)
+    sp = sc.spheres.copy()
+    sp["mat_type"] = 0
+    sp["mat_index"] = 0
+    blobs["spheres"] = sp
+    lights = sc.lights.copy()
+    lights["v"][0] = (0.25, 0.5, 2.0)
+    blobs["lights"] = lights
+    s2 = orc.Scene(blobs)
+    acc, st = orc.render(s2, s2.camera(48, 27), 48, 27, [1, 2, 3])
+    assert st["rays"] == st["paths"] == 48 * 27 * 3
+    per_frame_hit = np.isclose(acc[..., 2], 6.0)  # 3 frames x 2.0
+    assert per_frame_hit.any()
+    assert np.all(acc[per_frame_hit][:, :3] == np.float32([0.75, 1.5, 6.0]))
+    assert np.all(acc[..., 3] == 1.0)
+
+
+def test_primary_visit_counts_match_survey_probe(orc):
+    # scene1 primary rays at 1280x720: 27.5 interior / 6.5 leaf visits per ray and the hit mix
+    # (sky 35.2 %, lambertian 41.5 %, glass 8.4 %, metal 8.4 %, light 6.5 %) were measured
+    # independently with a numpy probe of the reference's traversal rule.
+    sc = orc.Scene.from_ron(os.path.join(FIXTURES, "scene1.ron"))
+    _, st = orc.render(sc, sc.camera(1280, 720), 1280, 720, [0x00C0FFEE], depth=0, threads=8)
+    n = st["rays"]
+    assert n == 1280 * 720
+    assert abs(st["interior_visits"] / n - 27.5) < 0.05
+    assert abs(st["leaf_visits"] / n - 6.5) < 0.06
+    assert abs(st["misses"] / n - 0.352) < 0.002
+    assert abs(st["bounce_lambertian"] / n - 0.415) < 0.002
+    assert abs(st["bounce_glass"] / n - 0.084) < 0.002
+    assert abs(st["bounce_metal"] / n - 0.084) < 0.002
+    assert abs(st["bounce_light"] / n - 0.065) < 0.002
+
+
+def test_oracle_reproduces_committed_goldens(orc):
+    g = np.load(os.path.join(GOLDEN, "golden.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "golden.json")))
+    L = orc.lib()
+    for i, s in enumerate(g["rng_seeds"]):
+        st = C.c_uint32(int(s))
+        assert [L.orc_randu(C.byref(st)) for _ in range(16)] == [int(x) for x in g["rng_draws"][i]]
+    for p, v in zip(g["hash_points"], g["hash_values"]):
+        assert L.orc_pixel_seed(0, *[int(x) for x in p]) == int(v)
+    for x, y in zip(g["sin_x"], g["sin_y"]):
+        assert np.float32(L.orc_det_sin(float(x))) == y
+        assert abs(float(y) - np.sin(np.float64(x))) < 3e-7
+    for name in ("scene1", "scene2", "scene3"):
+        sc = orc.Scene.from_ron(os.path.join(FIXTURES, name + ".ron"))
+        assert bits_equal(sc.camera(64, 36), g[name + "_camera_16x9"])
+        acc, st = orc.render(sc, sc.camera(64, 36), 64, 36, meta["seeds"])
+        assert bits_equal(acc, g[name + "_accum"])
+        assert st == meta[name + "_stats"]
+        acc2, _ = orc.render(sc, sc.camera(40, 30), 40, 30, meta["seeds"][:2], samples=3, depth=4)
+        assert bits_equal(acc2, g[name + "_accum_s3_d4"])
+        if name != "scene1":
+            assert sc.nodes.tobytes() == g[name + "_bvh"].tobytes()
+
+
+def test_threads_do_not_change_results(orc):
+    sc = orc.Scene.from_ron(os.path.join(FIXTURES, "scene2.ron"))
+    cam = sc.camera(32, 18)
+    a, sa = orc.render(sc, cam, 32, 18, [5, 6], threads=1)
+    b, sb = orc.render(sc, cam, 32, 18, [5, 6], threads=4)
+    assert bits_equal(a, b) and sa == sb
+    # frames accumulate in order: two calls == one call
+    c, _ = orc.render(sc, cam, 32, 18, [5])
+    c, _ = orc.render(sc, cam, 32, 18, [6], accum=c)
+    assert bits_equal(a, c)
