@@ -141,7 +141,7 @@ def main():
         out["roofline"] = {
             "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-            "kernel": "pt_render_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
+            "kernel": "pt_render_sched_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
             "nodes_per_ray": cs["nodes"] / cs["rays"], "sphere_tests_per_ray": cs["tests"] / cs["rays"],
             "note": "scene (22 KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
                     "vector FP32 figure (equal to the FP32 MFMA peak)",

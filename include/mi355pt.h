@@ -66,6 +66,8 @@ typedef struct mi355pt_stats {
     uint64_t tests;      /* ray-sphere tests                  (MI355PT_FLAG_COUNT only) */
     uint64_t accepted;   /* tests that replaced the closest   (MI355PT_FLAG_COUNT only) */
     uint64_t bounces[5]; /* light, lambertian, metal, glass, sky (MI355PT_FLAG_COUNT only) */
+    uint64_t phase[12];  /* per step kind (node, leaf, terminal, opaque, glass, idle): wave-level executions, lanes served
+                            (MI355PT_FLAG_COUNT only) */
     double render_ms;    /* device time of the path kernels, HIP events on the render stream */
     double resolve_ms;   /* device time of the accumulation kernels */
     uint32_t launches;   /* path-kernel launches */

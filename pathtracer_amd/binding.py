@@ -27,7 +27,8 @@ class Desc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("nodes", C.c_uint64), ("tests", C.c_uint64),
-                ("accepted", C.c_uint64), ("bounces", C.c_uint64 * 5), ("render_ms", C.c_double),
+                ("accepted", C.c_uint64), ("bounces", C.c_uint64 * 5), ("phase", C.c_uint64 * 12),
+                ("render_ms", C.c_double),
                 ("resolve_ms", C.c_double), ("launches", C.c_uint32), ("bvh_nodes", C.c_uint32),
                 ("bvh_depth", C.c_uint32), ("scene_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32),
                 ("reserved", C.c_uint32)]

@@ -290,6 +290,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
     out->paths = c->stats.paths, out->rays = c->stats.rays;
     out->nodes = c->stats.nodes, out->tests = c->stats.tests, out->accepted = c->stats.accepted;
     for (int k = 0; k < 5; k++) out->bounces[k] = c->stats.bounces[k];
+    for (int k = 0; k < 12; k++) out->phase[k] = c->stats.phase[k];
     out->render_ms = c->stats.render_ms, out->resolve_ms = c->stats.resolve_ms;
     out->launches = c->stats.launches;
     out->bvh_nodes = (uint32_t)c->bvh.nodes.size();

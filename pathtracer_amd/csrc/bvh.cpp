@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -203,10 +204,26 @@ Box empty_box() {
 }
 
 constexpr int kBins = 16;
-constexpr float kCostNode = 1.0f;    // one interior step: a 64-byte record and two slab tests
-constexpr float kCostSphere = 0.6f;  // one sphere test: a 16-byte record and the discriminant
+constexpr float kCostNode = 1.0f;  // one interior step: a 64-byte record and two slab tests
+
+// Tunables of the SAH builder; the environment overrides exist for experiments only.
+struct SahParams {
+    uint32_t max_leaf = MAX_LEAF_SPHERES;  // spheres per leaf, 1..4
+    float cost_sphere = 0.6f;              // one sphere test relative to one interior step
+    SahParams() {
+        if (const char* e = getenv("MI355PT_MAX_LEAF")) {
+            int v = atoi(e);
+            if (v >= 1 && v <= MAX_LEAF_SPHERES) max_leaf = (uint32_t)v;
+        }
+        if (const char* e = getenv("MI355PT_COST_SPHERE")) {
+            float v = (float)atof(e);
+            if (v > 0.0f && v < 100.0f) cost_sphere = v;
+        }
+    }
+};
 
 struct SahBuilder {
+    SahParams par;
     std::vector<Prim> prims;
     std::vector<TmpNode> tmp;
 
@@ -264,7 +281,7 @@ struct SahBuilder {
                     acc = unite(acc, bb[b]);
                     c += cnt[b];
                     if (c == 0 || right_cnt[b + 1] == 0) continue;
-                    float cost = kCostNode + kCostSphere *
+                    float cost = kCostNode + par.cost_sphere *
                                                  (half_area(acc) * (float)c +
                                                   right_area[b + 1] * (float)right_cnt[b + 1]) /
                                                  parent_area;
@@ -272,8 +289,8 @@ struct SahBuilder {
                 }
             }
         }
-        float leaf_cost = kCostSphere * (float)n;
-        if (!force_split && n <= (uint32_t)MAX_LEAF_SPHERES && (best_axis < 0 || leaf_cost <= best_cost))
+        float leaf_cost = par.cost_sphere * (float)n;
+        if (!force_split && n <= par.max_leaf && (best_axis < 0 || leaf_cost <= best_cost))
             return make_leaf();
 
         uint32_t mid;

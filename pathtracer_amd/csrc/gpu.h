@@ -17,6 +17,8 @@ struct RenderStats {
     uint64_t tests = 0;      // sphere tests                                  [counting launches only]
     uint64_t accepted = 0;   // sphere tests that replaced the closest record [counting launches only]
     uint64_t bounces[5] = {0, 0, 0, 0, 0};  // light, lambertian, metal, glass, sky  [counting only]
+    uint64_t phase[12] = {0};  // per step kind (node, leaf, terminal, opaque, glass, idle): wave-level
+                                                  // executions, lanes served  [counting only]
     double render_ms = 0.0;  // device time of the path kernels (HIP events on the render stream)
     double resolve_ms = 0.0; // device time of the frame-order accumulation kernels
     uint32_t launches = 0;

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <type_traits>
 #include <vector>
@@ -21,7 +22,6 @@
 namespace pt {
 namespace gpu {
 
-constexpr int BLOCK = 256;             // 4 waves
 constexpr uint32_t CHUNK_UNITS = 4;    // 64-path units taken from the queue per atomic
 
 #define PT_LDS(T) __attribute__((address_space(3))) T
@@ -48,13 +48,14 @@ struct LdsMem {
     }
 };
 // Per-lane traversal stack in LDS, entry-major so that lane l always hits bank l % 64.
+template <int BLK>
 struct LdsStack {
     uint32_t base;  // byte address of this lane's entry 0
     __device__ __forceinline__ void push(int sp, int32_t v) const {
-        *reinterpret_cast<PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLOCK * 4u)) = v;
+        *reinterpret_cast<PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLK * 4u)) = v;
     }
     __device__ __forceinline__ int32_t pop(int sp) const {
-        return *reinterpret_cast<const PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLOCK * 4u));
+        return *reinterpret_cast<const PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLK * 4u));
     }
 };
 
@@ -72,6 +73,9 @@ struct RenderParams {
     unsigned long long* counters;  // nodes, tests, accepted, bounce[5]
     uint32_t scene_lds_bytes;
     int32_t glass_always_draws;
+    uint64_t watchdog_ticks;  // 100 MHz ticks after which a wave gives up (scheduling-bug guard)
+    uint32_t thr[6];  // pt_render_sched_kernel: lanes that must wait for a step before it runs: node, leaf,
+                      // terminal, opaque, glass, idle
 };
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
@@ -88,13 +92,13 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-template <bool LDS_SCENE, bool COUNT>
-__global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) {
+template <bool LDS_SCENE, bool COUNT, int BLK>
+__global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
     if (LDS_SCENE) {
         const f4* src = reinterpret_cast<const f4*>(P.scene);
-        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLOCK)
+        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
         {
             typedef uint32_t w4 __attribute__((ext_vector_type(4)));
             *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = reinterpret_cast<const w4*>(src)[i];
@@ -105,7 +109,7 @@ __global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) 
     Mem mem;
     if constexpr (LDS_SCENE) mem.base = lds0;
     else mem.base = P.scene;
-    LdsStack stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
+    LdsStack<BLK> stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
 
     const CameraRegs cam = load_camera(P.cam);
     const float fw = (float)P.width, fh = (float)P.height;
@@ -181,7 +185,7 @@ __global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) 
         // ---- extend + scatter
         if (alive) {
             Hit hit;
-            closest_hit<Mem, LdsStack, COUNT>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
+            closest_hit<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
             nrays++;
             V3 radiance;
             uint32_t mat;
@@ -196,11 +200,14 @@ __global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) 
                 if (sample_i < P.samples) {
                     need_ray = true;
                 } else {
-                    const float fs = (float)P.samples;
                     f4 o4;
-                    o4.x = final_colour.x / fs;
-                    o4.y = final_colour.y / fs;
-                    o4.z = final_colour.z / fs;
+                    o4.x = final_colour.x, o4.y = final_colour.y, o4.z = final_colour.z;
+                    if (P.samples != 1) {  // x / 1.0f == x: the common case needs no division
+                        const float fs = (float)P.samples;
+                        o4.x = final_colour.x / fs;
+                        o4.y = final_colour.y / fs;
+                        o4.z = final_colour.z / fs;
+                    }
                     o4.w = (float)nrays;
                     P.frame_out[out_index] = o4;
                     alive = false;
@@ -216,6 +223,244 @@ __global__ void __launch_bounds__(BLOCK) pt_render_kernel(const RenderParams P) 
         for (int k = 0; k < 8; k++) {
             unsigned long long s = wave_sum(v[k]);
             if (lane == 0) atomicAdd(&P.counters[k], s);
+        }
+    }
+}
+
+// Wave-scheduled variant.  Every lane is a small state machine kept in Walk::cur -- interior node
+// pending, leaf pending, walk finished, one of three scatter classes pending, idle (needs a path or a
+// camera ray), exited -- and the wave runs one kind of step at a time, only when enough lanes wait
+// for it (ballot + popcount against a threshold).  Lanes in a thinly populated state wait until their
+// state fills up, so the long scatter bodies run with many lanes active instead of being serialised
+// over sparsely populated material branches, and the node loop stops when its population drops below
+// the threshold instead of dragging a few long walks along with most lanes idle.  When no state
+// reaches its threshold every non-empty state runs once, which guarantees progress.  Scheduling only
+// reorders work between independent paths; every path performs exactly the arithmetic of the
+// lockstep kernel.
+constexpr int32_t LANE_IDLE = INT32_MIN + 1;      // needs a path or the next sample's camera ray
+constexpr int32_t LANE_EXIT = INT32_MIN + 2;      // queue empty, nothing left to do
+constexpr int32_t LANE_TERMINAL = INT32_MIN + 3;  // path ends at this hit / miss; radiance still to add
+constexpr int32_t LANE_OPAQUE = INT32_MIN + 4;
+constexpr int32_t LANE_GLASS = INT32_MIN + 5;
+enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
+
+template <bool LDS_SCENE, bool COUNT, int BLK>
+__global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams P) {
+    extern __shared__ __align__(16) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
+    if (LDS_SCENE) {
+        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+        const w4* src = reinterpret_cast<const w4*>(P.scene);
+        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
+        __syncthreads();
+    }
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, PtrMem>::type;
+    Mem mem;
+    if constexpr (LDS_SCENE) mem.base = lds0;
+    else mem.base = P.scene;
+    LdsStack<BLK> stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
+
+    const CameraRegs cam = load_camera(P.cam);
+    const float fw = (float)P.width, fh = (float)P.height;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    bool have_path = false;  // idle with a path: only the next sample's camera ray is needed
+    PathState ps;
+    ps.o = ps.d = ps.colour = mk(0.0f, 0.0f, 0.0f);
+    ps.rng = 1u;
+    ps.bounce = 0;
+    Walk w;
+    walk_begin(w, ps.o, mk(1.0f, 1.0f, 1.0f));
+    w.cur = LANE_IDLE;
+    uint32_t mbits = 0;  // material word of the hit, valid in the scatter states
+    V3 final_colour = mk(0.0f, 0.0f, 0.0f);
+    uint32_t out_index = 0, pxy = 0, rays = 0;
+    int32_t sample_i = 0;
+    Counters cnt = {0, 0, 0};
+    uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
+    uint32_t ph_exec[PH_COUNT] = {0}, ph_lanes[PH_COUNT] = {0};  // COUNT: wave-level step executions
+
+    uint32_t next = 0, end = 0;  // wave-uniform: the wave's chunk of the path queue
+    bool exhausted = false;
+    bool force = false;
+
+    // One sample of a path has ended with `radiance`.
+    auto finish_sample = [&](V3 radiance) {
+        final_colour = final_colour + radiance;
+        sample_i++;
+        w.cur = LANE_IDLE;
+        if (sample_i >= P.samples) {
+            f4 o4;
+            o4.x = final_colour.x, o4.y = final_colour.y, o4.z = final_colour.z;
+            if (P.samples != 1) {  // x / 1.0f == x: the common case needs no division
+                const float fs = (float)P.samples;
+                o4.x = final_colour.x / fs;
+                o4.y = final_colour.y / fs;
+                o4.z = final_colour.z / fs;
+            }
+            o4.w = 0.0f;
+            P.frame_out[out_index] = o4;
+            have_path = false;
+        }
+    };
+    auto wants = [&](bool mine, int ph) -> bool {
+        const uint32_t n = (uint32_t)__popcll(__ballot(mine));
+        const bool go = n >= P.thr[ph] || (force && n);
+        if (COUNT && go) ph_exec[ph]++, ph_lanes[ph] += n;
+        return go;
+    };
+
+    const uint64_t t_start = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    for (uint32_t round = 0;; round++) {
+        // Watchdog: a scheduling bug must end the launch, not hang the GPU.
+        if ((round & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t_start > P.watchdog_ticks) {
+            if (lane == 0) atomicAdd(&P.counters[10], 1ull);
+            break;
+        }
+        bool ran = false;
+        // ---- interior nodes: keep stepping while enough lanes have one pending
+        if (wants(walk_is_node(w.cur), PH_NODE)) {
+            ran = true;
+            for (;;) {
+                if (walk_is_node(w.cur)) walk_node<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, w, cnt);
+                const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_node(w.cur)));
+                if (n < P.thr[PH_NODE]) break;
+                if (COUNT) ph_exec[PH_NODE]++, ph_lanes[PH_NODE] += n;
+            }
+        }
+        // ---- leaves
+        if (wants(walk_is_leaf(w.cur), PH_LEAF)) {
+            ran = true;
+            if (walk_is_leaf(w.cur)) walk_leaf<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+        }
+        // ---- finished walks: fetch the material word and sort the lane into its scatter class
+        if (w.cur == WALK_FINISHED) {
+            Hit hit;
+            hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+            mbits = hit_material(mem, P.L, hit);
+            const uint32_t cls = scatter_class(mbits, hit.back);
+            w.cur = cls == SC_OPAQUE ? LANE_OPAQUE : (cls == SC_GLASS ? LANE_GLASS : LANE_TERMINAL);
+            if (COUNT) {
+                const uint32_t type = mbits & 7u;
+                const uint32_t slot = type == MAT_SKY ? 4u : type;  // unknown (4) is not counted
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (slot == k && type != MAT_UNKNOWN) ? 1u : 0u;
+            }
+        }
+        // ---- paths that end here
+        if (wants(w.cur == LANE_TERMINAL, PH_TERMINAL)) {
+            ran = true;
+            if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
+        }
+        // ---- lambertian / metal
+        if (wants(w.cur == LANE_OPAQUE, PH_OPAQUE)) {
+            ran = true;
+            if (w.cur == LANE_OPAQUE) {
+                Hit hit;
+                hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+                V3 radiance;
+                if (scatter_opaque(mem, P.L, hit, mbits, ps, P.depth, radiance)) {
+                    finish_sample(radiance);
+                } else {
+                    walk_begin(w, ps.o, ps.d);
+                    rays++;
+                }
+            }
+        }
+        // ---- glass
+        if (wants(w.cur == LANE_GLASS, PH_GLASS)) {
+            ran = true;
+            if (w.cur == LANE_GLASS) {
+                Hit hit;
+                hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+                V3 radiance;
+                if (scatter_glass(mem, P.L, hit, mbits, ps, P.depth, P.glass_always_draws != 0, radiance)) {
+                    finish_sample(radiance);
+                } else {
+                    walk_begin(w, ps.o, ps.d);
+                    rays++;
+                }
+            }
+        }
+        // ---- idle lanes: take consecutive path ids from the wave's chunk, then start a sample
+        if (wants(w.cur == LANE_IDLE, PH_IDLE)) {
+            ran = true;
+            unsigned long long m = __ballot(w.cur == LANE_IDLE && !have_path);
+            while (m) {
+                if (next == end) {
+                    if (exhausted) break;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.work_counter, CHUNK_UNITS);
+                    base = __shfl(base, 0);
+                    if (base >= P.total_units) {
+                        exhausted = true;
+                        break;
+                    }
+                    next = base * 64u;
+                    end = min(base + CHUNK_UNITS, P.total_units) * 64u;
+                }
+                const uint32_t avail = end - next;
+                const uint32_t rank = lane_rank(m);
+                if (w.cur == LANE_IDLE && !have_path && rank < avail) {
+                    const uint32_t pid = next + rank;
+                    const uint32_t unit = pid >> 6, slot = pid & 63u;
+                    const uint32_t frame = unit / P.tiles_per_frame;
+                    const uint32_t tile = unit - frame * P.tiles_per_frame;
+                    uint32_t px, py;
+                    tile_pixel(tile, slot, P.tiles_x, px, py);
+                    if (px < P.width && py < P.height) {
+                        const uint32_t pix = py * P.width + px;
+                        ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
+                        out_index = frame * P.n_pix + pix;
+                        pxy = px | (py << 16);
+                        final_colour = mk(0.0f, 0.0f, 0.0f);
+                        sample_i = 0;
+                        have_path = true;
+                    }
+                }
+                next += min((uint32_t)__popcll(m), avail);
+                m = __ballot(w.cur == LANE_IDLE && !have_path);
+            }
+            if (w.cur == LANE_IDLE) {
+                if (have_path) {
+                    ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
+                    ps.o = cam.pos;
+                    ps.colour = mk(1.0f, 1.0f, 1.0f);
+                    ps.bounce = 0;
+                    walk_begin(w, ps.o, ps.d);
+                    rays++;
+                } else {
+                    w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
+                }
+            }
+        }
+        if (!ran) {
+            if (__ballot(w.cur != LANE_EXIT) == 0ull) break;
+            force = true;
+        } else {
+            force = false;
+        }
+    }
+
+    {
+        unsigned long long r = wave_sum((unsigned long long)rays);
+        if (lane == 0 && r) atomicAdd(&P.counters[9], r);
+    }
+    if (COUNT) {
+        unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
+                                   bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            unsigned long long s = wave_sum(v[k]);
+            if (lane == 0) atomicAdd(&P.counters[k], s);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < PH_COUNT; k++) {
+                atomicAdd(&P.counters[16 + 2 * k], (unsigned long long)ph_exec[k]);
+                atomicAdd(&P.counters[17 + 2 * k], (unsigned long long)ph_lanes[k]);
+            }
         }
     }
 }
@@ -359,7 +604,7 @@ bool synchronize(Device* d, std::string& err) {
 // LDS budget per workgroup that still leaves two workgroups per CU.
 constexpr uint32_t kLdsSceneLimit = 64u * 1024u;
 
-static uint32_t stack_bytes(const SceneLayout& L) { return std::max(1u, L.max_depth) * BLOCK * 4u; }
+static uint32_t stack_bytes(const SceneLayout& L, uint32_t block) { return std::max(1u, L.max_depth) * block * 4u; }
 
 bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err) {
     PT_HIP(hipSetDevice(d->id));
@@ -376,8 +621,8 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
     PT_HIP(hipMemcpy(d->scene, blob, layout.total_bytes, hipMemcpyHostToDevice));
     d->layout = layout;
     d->have_scene = true;
-    d->scene_in_lds = bytes + stack_bytes(layout) <= kLdsSceneLimit;
-    if (stack_bytes(layout) > 64u * 1024u) {
+    d->scene_in_lds = bytes + stack_bytes(layout, 256) <= kLdsSceneLimit;
+    if (stack_bytes(layout, 256) > 160u * 1024u) {
         err = "scene: BVH too deep for the traversal stack";
         d->have_scene = false;
         return false;
@@ -443,22 +688,31 @@ bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err
     return true;
 }
 
-template <bool LDS_SCENE, bool COUNT>
-static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, std::string& err) {
-    auto kern = pt_render_kernel<LDS_SCENE, COUNT>;
+template <bool LDS_SCENE, bool COUNT, int BLK>
+static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, bool lockstep, std::string& err) {
+    auto kern = lockstep ? pt_render_kernel<LDS_SCENE, COUNT, BLK> : pt_render_sched_kernel<LDS_SCENE, COUNT, BLK>;
     if (lds_bytes > 48u * 1024u)
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
     int per_cu = 0;
-    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLOCK, lds_bytes));
+    PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLK, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     uint32_t grid = (uint32_t)d->prop.multiProcessorCount * (uint32_t)per_cu;
     // never launch more waves than there are 64-path units
-    uint32_t max_blocks = (P.total_units + 3u) / 4u;
+    uint32_t max_blocks = (P.total_units + (BLK / 64) - 1u) / (BLK / 64);
     grid = std::max(1u, std::min(grid, max_blocks));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLOCK), lds_bytes, d->stream, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, P);
     PT_HIP(hipGetLastError());
     return true;
+}
+
+template <int BLK>
+static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_bytes, bool in_lds, bool count, bool lockstep,
+                              std::string& err) {
+    if (in_lds) return count ? launch_render<true, true, BLK>(d, P, lds_bytes, lockstep, err)
+                             : launch_render<true, false, BLK>(d, P, lds_bytes, lockstep, err);
+    return count ? launch_render<false, true, BLK>(d, P, lds_bytes, lockstep, err)
+                 : launch_render<false, false, BLK>(d, P, lds_bytes, lockstep, err);
 }
 
 static hipEvent_t get_event(Device* d, size_t i) {
@@ -536,9 +790,39 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     P.work_counter = d->work_counter;
     P.counters = d->counters;
     P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
+    // Development switches (not part of the ABI): MI355PT_KERNEL=lockstep selects the simple kernel,
+    // MI355PT_SCHED="node,leaf,terminal,opaque,glass,idle" overrides the step thresholds.
+    const char* kenv = getenv("MI355PT_KERNEL");
+    const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
+    P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
+    const uint32_t default_thr[6] = {16, 16, 24, 24, 8, 32};
+    for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
+    if (const char* senv = getenv("MI355PT_SCHED")) {
+        unsigned t[6];
+        if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
+            for (int k = 0; k < 6; k++) P.thr[k] = t[k] < 1 ? 1 : (t[k] > 64 ? 64 : t[k]);
+    }
     const bool in_lds = d->scene_in_lds;
     P.scene_lds_bytes = in_lds ? (uint32_t)(((size_t)d->layout.total_bytes + 15u) & ~(size_t)15u) : 0u;
-    const uint32_t lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout);
+    // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
+    // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
+    // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
+    const size_t lds_cu = 160u * 1024u;
+    auto waves_per_cu = [&](uint32_t blk) {
+        size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk);
+        size_t blocks = per_block ? lds_cu / per_block : 8;
+        return std::min<size_t>(blocks * (blk / 64), 24);  // 24: the register budget of these kernels
+    };
+    uint32_t block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
+    if (const char* benv = getenv("MI355PT_BLOCK")) {
+        int v = atoi(benv);
+        if (v == 256 || v == 512 || v == 1024) block = (uint32_t)v;
+    }
+    const uint32_t lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
+    if (lds_bytes > lds_cu) {
+        err = "render: traversal stacks do not fit in LDS (tree too deep)";
+        return false;
+    }
 
     size_t ev = 0;
     uint32_t launches = 0;
@@ -549,8 +833,9 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
         PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
         bool ok;
-        if (in_lds) ok = cfg.count ? launch_render<true, true>(d, P, lds_bytes, err) : launch_render<true, false>(d, P, lds_bytes, err);
-        else ok = cfg.count ? launch_render<false, true>(d, P, lds_bytes, err) : launch_render<false, false>(d, P, lds_bytes, err);
+        if (block == 512) ok = launch_render_blk<512>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
+        else if (block == 1024) ok = launch_render_blk<1024>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
+        else ok = launch_render_blk<256>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
         if (!ok) return false;
         PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
         hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum,
@@ -567,13 +852,18 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
         stats.render_ms += a;
         stats.resolve_ms += b;
     }
-    unsigned long long host_counters[9];
+    unsigned long long host_counters[28];
     PT_HIP(hipMemcpy(host_counters, d->counters, sizeof host_counters, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 12; k++) stats.phase[k] = host_counters[16 + k];
     stats.nodes = host_counters[0];
     stats.tests = host_counters[1];
     stats.accepted = host_counters[2];
     for (int k = 0; k < 5; k++) stats.bounces[k] = host_counters[3 + k];
-    stats.rays = host_counters[8];
+    stats.rays = host_counters[8] + host_counters[9];
+    if (host_counters[10]) {
+        err = "render: kernel watchdog expired (" + std::to_string(host_counters[10]) + " waves gave up); the accumulator is incomplete";
+        return false;
+    }
     stats.paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * n_frames;
     stats.launches += launches;
     return true;

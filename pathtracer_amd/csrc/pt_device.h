@@ -23,6 +23,17 @@
 #define PT_FN inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PT_FMA(a, b, c) __builtin_fmaf(a, b, c)
+#define PT_RCP(x) __builtin_amdgcn_rcpf(x)
+// 2*x - 1: the doubling is exact, so the fused form has the same value as multiply-then-subtract.
+#define PT_TWICE_MINUS_ONE(x) __builtin_fmaf(2.0f, (x), -1.0f)
+#else
+#define PT_FMA(a, b, c) fmaf(a, b, c)
+#define PT_RCP(x) (1.0f / (x))
+#define PT_TWICE_MINUS_ONE(x) (2.0f * (x) - 1.0f)
+#endif
+
 namespace pt {
 
 struct V3 {
@@ -62,9 +73,9 @@ PT_FN uint32_t randu(uint32_t& s) {
 PT_FN float randf(uint32_t& s) { return (float)randu(s) * 2.3283064365386963e-10f; }
 PT_FN V3 rand_in_sphere(uint32_t& s) {
     for (;;) {
-        float x = 2.0f * randf(s) - 1.0f;
-        float y = 2.0f * randf(s) - 1.0f;
-        float z = 2.0f * randf(s) - 1.0f;
+        float x = PT_TWICE_MINUS_ONE(randf(s));
+        float y = PT_TWICE_MINUS_ONE(randf(s));
+        float z = PT_TWICE_MINUS_ONE(randf(s));
         float l2 = x * x + y * y + z * z;
         if (l2 < 1.0f) return mk(x, y, z);
     }
@@ -126,8 +137,8 @@ PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, f
     float ry = randf(rng);
     float ux = ((float)px + rx) / fw;
     float uy = ((float)py + ry) / fh;
-    float nx = ux * 2.0f - 1.0f;
-    float ny = -(uy * 2.0f - 1.0f);
+    float nx = PT_TWICE_MINUS_ONE(ux);
+    float ny = -PT_TWICE_MINUS_ONE(uy);
     return normalize3(cam.center + cam.horizontal * nx + cam.vertical * ny - cam.pos);
 }
 
@@ -152,128 +163,149 @@ struct Counters {
     uint32_t nodes, tests, accepted;
 };
 
-constexpr int32_t TRAVERSAL_DONE = INT32_MIN;
 
 // Slab test of one child box against the ray (inv = 1/dir, ood = org/dir), clipped to [0, tcap].
 PT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 ood, float tcap,
                 float& tnear) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#define PT_FMA(a, b, c) __builtin_fmaf(a, b, c)
-#else
-#define PT_FMA(a, b, c) fmaf(a, b, c)
-#endif
     float x0 = PT_FMA(lox, inv.x, -ood.x), x1 = PT_FMA(hix, inv.x, -ood.x);
     float y0 = PT_FMA(loy, inv.y, -ood.y), y1 = PT_FMA(hiy, inv.y, -ood.y);
     float z0 = PT_FMA(loz, inv.z, -ood.z), z1 = PT_FMA(hiz, inv.z, -ood.z);
-#undef PT_FMA
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcap));
     tnear = tn;
     return tn <= tf;
 }
 
-// Closest hit (compute.wgsl:208-268 + 115-150) over the internal BVH.  The result is the sphere
-// with the smallest accepted root; on an exact tie the sphere that comes later in the reference's
-// own flattened order wins (its walk replaces the record when t == closest.t), which is what the
-// tie rank in `info` encodes.  Traversal order and tree shape therefore do not affect the result.
-template <class Mem, class Stack, bool COUNT>
-PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
-                       Counters& cnt) {
-    // Reciprocal direction for the slab tests only; tiny components are clamped so no inf/NaN
-    // enters the box arithmetic (the clamp never reaches a pixel value).
+// Closest hit (compute.wgsl:208-268 + 115-150) over the internal BVH, as a resumable walk: the
+// kernels advance many rays one step at a time and choose, per wave, which kind of step to run.
+// The result is the sphere with the smallest accepted root; on an exact tie the sphere that comes
+// later in the reference's own flattened order wins (its walk replaces the record when
+// t == closest.t), which is what the tie rank in `info` encodes.  Traversal order and tree shape
+// therefore do not affect the result.
+struct Walk {
+    V3 inv, ood;       // reciprocal direction and origin * inv, for the slab tests only
+    float best_t;
+    int32_t best_idx;  // leaf-order sphere index, -1 = none yet
+    bool best_back;
+    int32_t cur;       // >= 0 interior node to visit; leaf link (see walk_is_leaf); or WALK_FINISHED
+    int32_t sp;        // entries on the traversal stack
+};
+// Leaf links are ~(first | (count-1) << 28) and lie in [-2^30, -1]; values below are free for
+// the walk's end marker and for the kernels' own lane states.
+constexpr int32_t WALK_FINISHED = INT32_MIN;
+PT_FN bool walk_is_node(int32_t cur) { return cur >= 0; }
+PT_FN bool walk_is_leaf(int32_t cur) { return (uint32_t)cur >= 0xC0000000u; }
+
+PT_FN void walk_begin(Walk& w, V3 o, V3 d) {
+    // Tiny direction components are clamped so no inf/NaN enters the box arithmetic; the
+    // reciprocal may be approximate.  Neither reaches a pixel value: boxes only cull, and every
+    // box carries the reference's 0.01 padding.
     V3 dc = d;
     if (fabsf(dc.x) < 1e-20f) dc.x = copysignf(1e-20f, dc.x);
     if (fabsf(dc.y) < 1e-20f) dc.y = copysignf(1e-20f, dc.y);
     if (fabsf(dc.z) < 1e-20f) dc.z = copysignf(1e-20f, dc.z);
-    V3 inv = mk(1.0f / dc.x, 1.0f / dc.y, 1.0f / dc.z);
-    V3 ood = mk(o.x * inv.x, o.y * inv.y, o.z * inv.z);
+    w.inv = mk(PT_RCP(dc.x), PT_RCP(dc.y), PT_RCP(dc.z));
+    w.ood = mk(o.x * w.inv.x, o.y * w.inv.y, o.z * w.inv.z);
+    w.best_t = INFINITY;
+    w.best_idx = -1;
+    w.best_back = false;
+    w.cur = 0;  // a scene has >= 2 spheres, so node 0 is interior
+    w.sp = 0;
+}
 
-    float best_t = INFINITY;
-    int32_t best_idx = -1;
-    bool best_back = false;
-    uint32_t best_rank = 0;
+template <class Stack>
+PT_FN void walk_pop(Walk& w, Stack& stack) {
+    if (w.sp > 0) {
+        w.sp--;
+        w.cur = stack.pop(w.sp);
+    } else {
+        w.cur = WALK_FINISHED;
+    }
+}
 
-    int32_t cur = 0;  // a scene has >= 2 spheres, so node 0 is interior
-    int sp = 0;
-    for (;;) {
-        while (cur >= 0) {
-            uint32_t off = L.off_nodes + (uint32_t)cur * 64u;
-            f4 q0 = mem.template load<f4>(off);
-            f4 q1 = mem.template load<f4>(off + 16);
-            f4 q2 = mem.template load<f4>(off + 32);
-            u2 ch = mem.template load<u2>(off + 48);
-            if (COUNT) cnt.nodes++;
-            float t0, t1;
-            bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, inv, ood, best_t, t0);
-            bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, inv, ood, best_t, t1);
-            int32_t c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
-            if (h0 && h1) {
-                bool swap = t1 < t0;
-                int32_t nearc = swap ? c1 : c0;
-                int32_t farc = swap ? c0 : c1;
-                stack.push(sp, farc);
-                sp++;
-                cur = nearc;
-            } else if (h0) {
-                cur = c0;
-            } else if (h1) {
-                cur = c1;
-            } else if (sp > 0) {
-                sp--;
-                cur = stack.pop(sp);
-            } else {
-                cur = TRAVERSAL_DONE;
+// One interior node: both child boxes, near child first, far child pushed.  Requires a node.
+template <class Mem, class Stack, bool COUNT>
+PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, Counters& cnt) {
+    uint32_t off = L.off_nodes + (uint32_t)w.cur * 64u;
+    f4 q0 = mem.template load<f4>(off);
+    f4 q1 = mem.template load<f4>(off + 16);
+    f4 q2 = mem.template load<f4>(off + 32);
+    u2 ch = mem.template load<u2>(off + 48);
+    if (COUNT) cnt.nodes++;
+    float t0, t1;
+    bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, w.inv, w.ood, w.best_t, t0);
+    bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, w.inv, w.ood, w.best_t, t1);
+    int32_t c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
+    if (h0 && h1) {
+        bool swap = t1 < t0;
+        stack.push(w.sp, swap ? c0 : c1);
+        w.sp++;
+        w.cur = swap ? c1 : c0;
+    } else if (h0) {
+        w.cur = c0;
+    } else if (h1) {
+        w.cur = c1;
+    } else {
+        walk_pop(w, stack);
+    }
+}
+
+// Every sphere of the current leaf (compute.wgsl:116-135 with the running closest t), then the
+// next stack entry.  Requires a leaf.
+template <class Mem, class Stack, bool COUNT>
+PT_FN void walk_leaf(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, V3 o, V3 d, Counters& cnt) {
+    uint32_t ref = ~(uint32_t)w.cur;
+    uint32_t first = ref & LEAF_FIRST_MASK;
+    uint32_t count = (ref >> LEAF_COUNT_SHIFT) + 1u;
+    for (uint32_t k = 0; k < count; k++) {
+        uint32_t si = first + k;
+        f4 s = mem.template load<f4>(L.off_spheres + si * 16u);
+        if (COUNT) cnt.tests++;
+        V3 oc = o - mk(s.x, s.y, s.z);
+        float half_b = dot3(oc, d);
+        float c = dot3(oc, oc) - (s.w * s.w);
+        float disc = half_b * half_b - c;
+        if (!(disc < 0.0f)) {
+            float sq = sqrtf(disc);
+            float t = -half_b - sq;
+            bool back = false;
+            if (t < 0.0f) {
+                t = -half_b + sq;
+                back = true;
             }
-        }
-        if (cur == TRAVERSAL_DONE) break;
-        {
-            uint32_t ref = ~(uint32_t)cur;
-            uint32_t first = ref & LEAF_FIRST_MASK;
-            uint32_t count = (ref >> LEAF_COUNT_SHIFT) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
-                uint32_t si = first + k;
-                f4 s = mem.template load<f4>(L.off_spheres + si * 16u);
-                if (COUNT) cnt.tests++;
-                // compute.wgsl:116-135
-                V3 oc = o - mk(s.x, s.y, s.z);
-                float half_b = dot3(oc, d);
-                float c = dot3(oc, oc) - (s.w * s.w);
-                float disc = half_b * half_b - c;
-                if (!(disc < 0.0f)) {
-                    float sq = sqrtf(disc);
-                    float t = -half_b - sq;
-                    bool back = false;
-                    if (t < 0.0f) {
-                        t = -half_b + sq;
-                        back = true;
-                    }
-                    if (!(t < 0.0f)) {
-                        bool take = t < best_t;
-                        if (t == best_t && best_idx >= 0) {
-                            uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
-                            take = rank > best_rank;
-                        }
-                        if (take) {
-                            if (COUNT) cnt.accepted++;
-                            best_t = t;
-                            best_idx = (int32_t)si;
-                            best_back = back;
-                            best_rank = mem.template load<u2>(L.off_info + si * 8u).y;
-                        }
-                    }
+            if (!(t < 0.0f)) {
+                bool take = t < w.best_t;
+                if (t == w.best_t && w.best_idx >= 0) {
+                    uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
+                    uint32_t best_rank = mem.template load<u2>(L.off_info + (uint32_t)w.best_idx * 8u).y;
+                    take = rank > best_rank;
+                }
+                if (take) {
+                    if (COUNT) cnt.accepted++;
+                    w.best_t = t;
+                    w.best_idx = (int32_t)si;
+                    w.best_back = back;
                 }
             }
         }
-        if (sp > 0) {
-            sp--;
-            cur = stack.pop(sp);
-        } else {
-            break;
-        }
     }
-    hit.t = best_t;
-    hit.idx = best_idx;
-    hit.back = best_back;
+    walk_pop(w, stack);
+}
+
+// Whole query, one ray at a time.
+template <class Mem, class Stack, bool COUNT>
+PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
+                       Counters& cnt) {
+    Walk w;
+    walk_begin(w, o, d);
+    for (;;) {
+        while (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT>(mem, L, stack, w, cnt);
+        if (w.cur == WALK_FINISHED) break;
+        walk_leaf<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
+    }
+    hit.t = w.best_t;
+    hit.idx = w.best_idx;
+    hit.back = w.best_back;
 }
 
 // ---- materials: compute.wgsl:197-207, 269-368 ---------------------------------------------------
@@ -302,83 +334,122 @@ struct PathState {
     int32_t bounce; // loop index i of trace_path
 };
 
-// One iteration of trace_path's loop after the closest-hit query.  Returns true when the path
-// ends; `radiance` is then what trace_path returns.
+// One iteration of trace_path's loop after the closest-hit query, split by what the hit needs so a
+// wave can run each kind with many lanes at once:
+//   SC_TERMINAL  the path ends here: sky, light, back face of an opaque sphere, unknown material
+//   SC_OPAQUE    lambertian or metal front face: one rand_in_sphere, new direction, albedo
+//   SC_GLASS     dielectric: reflect or refract
+enum : uint32_t { SC_TERMINAL = 0, SC_OPAQUE = 1, SC_GLASS = 2 };
+
+// Material word of the hit sphere (type | index << 3); MAT_SKY for a miss.
+constexpr uint32_t MAT_UNKNOWN = 4, MAT_SKY = 5;
 template <class Mem>
-PT_FN bool scatter(const Mem& mem, const SceneLayout& L, const Hit& hit, PathState& ps, int32_t depth,
-                   bool glass_always_draws, V3& radiance, uint32_t& mat_out) {
-    if (hit.idx < 0) {
-        mat_out = 4u;
-        radiance = ps.colour * sky(ps.d.y);
-        return true;
+PT_FN uint32_t hit_material(const Mem& mem, const SceneLayout& L, const Hit& hit) {
+    if (hit.idx < 0) return MAT_SKY;
+    return mem.template load<u2>(L.off_info + (uint32_t)hit.idx * 8u).x;
+}
+PT_FN uint32_t scatter_class(uint32_t mbits, bool back) {
+    uint32_t type = mbits & 7u;
+    if (type == MAT_GLASS) return SC_GLASS;
+    if ((type == MAT_LAMBERTIAN || type == MAT_METAL) && !back) return SC_OPAQUE;
+    return SC_TERMINAL;
+}
+
+// compute.wgsl:296-300, 303-305, 313-315, 356-358, 361-363: what trace_path returns.
+template <class Mem>
+PT_FN V3 scatter_terminal(const Mem& mem, const SceneLayout& L, uint32_t mbits, const PathState& ps) {
+    uint32_t type = mbits & 7u;
+    if (type == MAT_SKY) return ps.colour * sky(ps.d.y);
+    if (type == MAT_LIGHT) {
+        f4 m = mem.template load<f4>(L.off_lights + (mbits >> 3) * 16u);
+        return ps.colour * mk(m.x, m.y, m.z);
     }
+    return mk(0.0f, 0.0f, 0.0f);
+}
+
+// compute.wgsl:138-147 (hit position, outward / flipped normal) for the sphere that was hit.
+template <class Mem>
+PT_FN void hit_frame(const Mem& mem, const SceneLayout& L, const Hit& hit, const PathState& ps, V3& pos, V3& norm) {
     f4 s = mem.template load<f4>(L.off_spheres + (uint32_t)hit.idx * 16u);
-    uint32_t mbits = mem.template load<u2>(L.off_info + (uint32_t)hit.idx * 8u).x;
-    uint32_t mat_type = mbits & 7u, mat_index = mbits >> 3;
-    mat_out = mat_type;
-    // compute.wgsl:138-147: hit position and outward / flipped normal
-    V3 pos = ps.o + (ps.d * hit.t);
-    V3 norm = normalize3(pos - mk(s.x, s.y, s.z));
+    pos = ps.o + (ps.d * hit.t);
+    norm = normalize3(pos - mk(s.x, s.y, s.z));
     if (hit.back) norm = -norm;
-    const float dist = 0.001f;
-    V3 new_pos = pos + norm * dist;
-    if (mat_type == MAT_LIGHT) {
-        f4 m = mem.template load<f4>(L.off_lights + mat_index * 16u);
-        radiance = ps.colour * mk(m.x, m.y, m.z);
-        return true;
-    } else if (mat_type == MAT_LAMBERTIAN) {
-        if (hit.back) {
-            radiance = mk(0.0f, 0.0f, 0.0f);
-            return true;
-        }
-        f4 m = mem.template load<f4>(L.off_lambertians + mat_index * 16u);
-        V3 scattered = normalize3(norm + rand_in_sphere(ps.rng));
-        ps.o = new_pos;
-        ps.d = scattered;
-        ps.colour = ps.colour * mk(m.x, m.y, m.z);
-    } else if (mat_type == MAT_METAL) {
-        if (hit.back) {
-            radiance = mk(0.0f, 0.0f, 0.0f);
-            return true;
-        }
-        f4 m = mem.template load<f4>(L.off_metals + mat_index * 16u);
-        V3 reflected = normalize3(reflect3(ps.d, norm) + rand_in_sphere(ps.rng) * m.w);
-        ps.o = new_pos;
-        ps.d = reflected;
-        ps.colour = ps.colour * mk(m.x, m.y, m.z);
-    } else if (mat_type == MAT_GLASS) {
-        float mir = mem.template load<float>(L.off_glass + mat_index * 4u);
-        float ir = hit.back ? mir : 1.0f / mir;
-        float cos_theta = fminf(dot3(-ps.d, norm), 1.0f);
-        float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
-        bool cannot_refract = ir * sin_theta > 1.0f;
-        bool do_reflect = cannot_refract;
-        if (glass_always_draws || !cannot_refract) {
-            float refl = reflectance(cos_theta, ir);
-            float rnd = randf(ps.rng);
-            do_reflect = cannot_refract || refl > rnd;
-        }
-        V3 dir, np;
-        if (do_reflect) {
-            dir = reflect3(ps.d, norm);
-            np = pos + norm * dist;
-        } else {
-            dir = refract3(ps.d, norm, ir);
-            np = pos - norm * dist;
-        }
-        ps.o = np;
-        ps.d = normalize3(dir);
-    } else {  // unknown material: compute.wgsl:356-358
-        radiance = mk(0.0f, 0.0f, 0.0f);
-        return true;
-    }
+}
+
+// Loop bookkeeping after a scatter (compute.wgsl:365 and the loop condition at :289).  Returns true
+// when the path ends because the depth ran out; trace_path then returns colour * (0,0,0).
+PT_FN bool next_bounce(PathState& ps, int32_t depth, V3& radiance) {
     ps.bounce += 1;
     if (ps.bounce > depth) {
-        // trace_path's loop condition fails with light still (0,0,0)
         radiance = ps.colour * mk(0.0f, 0.0f, 0.0f);
         return true;
     }
     return false;
+}
+
+// compute.wgsl:302-326.  Lambertian: normalize(norm + r).  Metal: normalize(reflect(d, norm) + r * roughness).
+// Both are computed as normalize(base + r * scale) with scale = 1 for lambertian, which is the same
+// value (r * 1.0f == r exactly).
+template <class Mem>
+PT_FN bool scatter_opaque(const Mem& mem, const SceneLayout& L, const Hit& hit, uint32_t mbits, PathState& ps,
+                          int32_t depth, V3& radiance) {
+    V3 pos, norm;
+    hit_frame(mem, L, hit, ps, pos, norm);
+    const bool metal = (mbits & 7u) == MAT_METAL;
+    f4 m = mem.template load<f4>((metal ? L.off_metals : L.off_lambertians) + (mbits >> 3) * 16u);
+    V3 base = metal ? reflect3(ps.d, norm) : norm;
+    float scale = metal ? m.w : 1.0f;
+    V3 dir = normalize3(base + rand_in_sphere(ps.rng) * scale);
+    ps.o = pos + norm * 0.001f;
+    ps.d = dir;
+    ps.colour = ps.colour * mk(m.x, m.y, m.z);
+    return next_bounce(ps, depth, radiance);
+}
+
+// compute.wgsl:328-355
+template <class Mem>
+PT_FN bool scatter_glass(const Mem& mem, const SceneLayout& L, const Hit& hit, uint32_t mbits, PathState& ps,
+                         int32_t depth, bool glass_always_draws, V3& radiance) {
+    V3 pos, norm;
+    hit_frame(mem, L, hit, ps, pos, norm);
+    const float dist = 0.001f;
+    float mir = mem.template load<float>(L.off_glass + (mbits >> 3) * 4u);
+    float ir = hit.back ? mir : 1.0f / mir;
+    float cos_theta = fminf(dot3(-ps.d, norm), 1.0f);
+    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    bool cannot_refract = ir * sin_theta > 1.0f;
+    bool do_reflect = cannot_refract;
+    if (glass_always_draws || !cannot_refract) {
+        float refl = reflectance(cos_theta, ir);
+        float rnd = randf(ps.rng);
+        do_reflect = cannot_refract || refl > rnd;
+    }
+    V3 dir, np;
+    if (do_reflect) {
+        dir = reflect3(ps.d, norm);
+        np = pos + norm * dist;
+    } else {
+        dir = refract3(ps.d, norm, ir);
+        np = pos - norm * dist;
+    }
+    ps.o = np;
+    ps.d = normalize3(dir);
+    return next_bounce(ps, depth, radiance);
+}
+
+// All of the above for one ray.  Returns true when the path ends; `radiance` is then what
+// trace_path returns.  mat_out: 0..3 material, 4 sky, 5 unknown.
+template <class Mem>
+PT_FN bool scatter(const Mem& mem, const SceneLayout& L, const Hit& hit, PathState& ps, int32_t depth,
+                   bool glass_always_draws, V3& radiance, uint32_t& mat_out) {
+    const uint32_t mbits = hit_material(mem, L, hit);
+    const uint32_t type = mbits & 7u;
+    mat_out = type == MAT_SKY ? 4u : (type == MAT_UNKNOWN ? 5u : type);
+    const uint32_t cls = scatter_class(mbits, hit.back);
+    if (cls == SC_OPAQUE) return scatter_opaque(mem, L, hit, mbits, ps, depth, radiance);
+    if (cls == SC_GLASS) return scatter_glass(mem, L, hit, mbits, ps, depth, glass_always_draws, radiance);
+    radiance = scatter_terminal(mem, L, mbits, ps);
+    return true;
 }
 
 // 8x8 pixel tiles: work unit u of a frame covers tile (u % tiles_x, u / tiles_x); slot in [0,64).
