@@ -38,6 +38,24 @@ def bytes_per_launch(st):
     return st["nodes"] * 64 + st["tests"] * 16 + hits * 40
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter passes
+    (profiles/*/pmc_summary.json, same bench command): 2 x FETCH_SIZE + WRITE_SIZE, in KiB -> bytes.
+    FETCH_SIZE under-reports wide reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for name, v in d.items():
+            c = v.get("counters_avg_per_dispatch", {})
+            if kernel_prefix in name and "false" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                best = (f, (2.0 * c["FETCH_SIZE"]["avg"] + c["WRITE_SIZE"]["avg"]) * 1024.0)
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +158,7 @@ def main():
         ach = fl / (kernel_ms * 1e-3) / 1e12
         out["roofline"] = {
             "bound": "valu", "achieved": ach, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+            "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None, "traffic_unit": "bytes/launch",
             "kernel": "pt_render_sched_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
             "nodes_per_ray": cs["nodes"] / cs["rays"], "sphere_tests_per_ray": cs["tests"] / cs["rays"],
             "note": "scene (22 KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
@@ -148,6 +166,11 @@ def main():
             "scene_fetch": {"bytes_per_ray": by / cs["rays"], "achieved_GBps": by / (kernel_ms * 1e-3) / 1e9,
                             "served_from": "LDS" if cs["scene_in_lds"] else "L2/HBM", "hbm_peak_GBps": PEAK_HBM_GBS},
         }
+        tr = pmc_traffic("pt_render_sched_kernel")
+        if tr and os.path.basename(args.scene) == "scene1.ron" and (W, H, F) == (1920, 1080, 64):
+            out["roofline"]["traffic"] = tr[1]
+            out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
+            out["roofline"]["hbm_GBps_from_traffic"] = tr[1] / (kernel_ms * 1e-3) / 1e9
         # ---- converged-image parity against the reference's own render (outside the timed region)
         if not args.no_rmse and os.path.basename(args.scene) == "scene1.ron":
             try:

@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libmi355pt.so")
+# MI355PT_LIB: load another build of the same library (A/B measurements of two builds)
+_LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(_HERE, "libmi355pt.so")
 
 BVH_SAH = 0
 BVH_REFERENCE = 1

@@ -224,6 +224,8 @@ PT_FN void walk_pop(Walk& w, Stack& stack) {
 }
 
 // One interior node: both child boxes, near child first, far child pushed.  Requires a node.
+// (A straight-line variant with selects, an unconditional far-child store and an up-front pop was
+// measured 9 % slower: the step is bound by vector instruction issue, and the branches skip work.)
 template <class Mem, class Stack, bool COUNT>
 PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, Counters& cnt) {
     uint32_t off = L.off_nodes + (uint32_t)w.cur * 64u;

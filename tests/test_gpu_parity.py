@@ -279,3 +279,34 @@ def test_converged_image_matches_reference_png(pa):
     rmse = np.sqrt(np.mean((img - ref) ** 2))
     print("RMSE vs mdimg.png (8-bit units):", rmse)
     assert rmse <= 3.0
+
+
+def test_accumulator_is_visible_to_torch_without_a_copy(pa):
+    # the multi-GPU path hands the library's accumulator to torch.distributed; run it the way
+    # bench.py does (torch first, then the library) in a fresh process
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch, numpy as np
+import pathtracer_amd as pa
+from pathtracer_amd import parallel
+sc = pa.load_ron_scene("fixtures/scene2.ron")
+with pa.Renderer(sc, pa.Settings(), 64, 36) as r:
+    r.render(seeds=[1, 2, 3])
+    t = parallel.accum_tensor(r, 0)
+    host = r.read_accum()
+    assert t.shape == (36, 64, 4) and t.is_cuda
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), host.view(np.uint32))
+    t[..., 3] = 7.0                      # torch writes land in the library's buffer
+    torch.cuda.synchronize()
+    assert np.all(r.read_accum()[..., 3] == 7.0)
+    parallel.reduce_accum(t, 1)
+    torch.cuda.synchronize()
+    assert np.all(r.read_accum()[..., 3] == 1.0)
+print("ok")
+'''
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
