@@ -76,6 +76,8 @@ struct RenderParams {
     uint64_t watchdog_ticks;  // 100 MHz ticks after which a wave gives up (scheduling-bug guard)
     uint32_t thr[6];  // pt_render_sched_kernel: lanes that must wait for a step before it runs: node, leaf,
                       // terminal, opaque, glass, idle
+    float inv_tiles_x, inv_tiles_per_frame;
+    uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
 };
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
@@ -405,10 +407,15 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (w.cur == LANE_IDLE && !have_path && rank < avail) {
                     const uint32_t pid = next + rank;
                     const uint32_t unit = pid >> 6, slot = pid & 63u;
-                    const uint32_t frame = unit / P.tiles_per_frame;
-                    const uint32_t tile = unit - frame * P.tiles_per_frame;
-                    uint32_t px, py;
-                    tile_pixel(tile, slot, P.tiles_x, px, py);
+                    uint32_t frame, tile, tx, ty;
+                    if (P.small_ids) {  // uniform: every id below 2^24, float-reciprocal division
+                        divmod24(unit, P.tiles_per_frame, P.inv_tiles_per_frame, frame, tile);
+                        divmod24(tile, P.tiles_x, P.inv_tiles_x, ty, tx);
+                    } else {
+                        frame = unit / P.tiles_per_frame, tile = unit - frame * P.tiles_per_frame;
+                        ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                    }
+                    const uint32_t px = tx * 8u + (slot & 7u), py = ty * 8u + (slot >> 3);
                     if (px < P.width && py < P.height) {
                         const uint32_t pix = py * P.width + px;
                         ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
@@ -795,6 +802,8 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     const char* kenv = getenv("MI355PT_KERNEL");
     const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
+    P.inv_tiles_x = 1.0f / (float)tiles_x;
+    P.inv_tiles_per_frame = 1.0f / (float)tiles;
     const uint32_t default_thr[6] = {16, 16, 24, 24, 8, 32};
     for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {
@@ -829,6 +838,7 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
         const uint32_t nb = std::min(batch, n_frames - f0);
         P.total_units = nb * tiles;
+        P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = d->seeds + f0;
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
         PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));

@@ -71,14 +71,21 @@ PT_FN uint32_t randu(uint32_t& s) {
 }
 // f32(randu) / f32(0xffffffffu): the divisor rounds to 2^32, so this is an exact scaling.
 PT_FN float randf(uint32_t& s) { return (float)randu(s) * 2.3283064365386963e-10f; }
+// One iteration of rand_in_sphere's rejection loop (compute.wgsl:20-30): three draws in x, y, z
+// order; true when the point lies inside the unit ball.
+PT_FN bool rand_in_sphere_try(uint32_t& s, V3& v) {
+    float x = PT_TWICE_MINUS_ONE(randf(s));
+    float y = PT_TWICE_MINUS_ONE(randf(s));
+    float z = PT_TWICE_MINUS_ONE(randf(s));
+    v = mk(x, y, z);
+    float l2 = x * x + y * y + z * z;
+    return l2 < 1.0f;
+}
 PT_FN V3 rand_in_sphere(uint32_t& s) {
-    for (;;) {
-        float x = PT_TWICE_MINUS_ONE(randf(s));
-        float y = PT_TWICE_MINUS_ONE(randf(s));
-        float z = PT_TWICE_MINUS_ONE(randf(s));
-        float l2 = x * x + y * y + z * z;
-        if (l2 < 1.0f) return mk(x, y, z);
+    V3 v;
+    while (!rand_in_sphere_try(s, v)) {
     }
+    return v;
 }
 // Deterministic sine: nearest multiple of pi/2 removed in three Cody-Waite steps, then the
 // Cephes single-precision minimax polynomials; plain IEEE ops only.
@@ -165,6 +172,8 @@ struct Counters {
 
 
 // Slab test of one child box against the ray (inv = 1/dir, ood = org/dir), clipped to [0, tcap].
+// Scalar FMAs on purpose: the packed two-float form (v_pk_fma_f32) was measured 20 % slower for the
+// whole kernel on MI355X.
 PT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 inv, V3 ood, float tcap,
                 float& tnear) {
     float x0 = PT_FMA(lox, inv.x, -ood.x), x1 = PT_FMA(hix, inv.x, -ood.x);
@@ -392,20 +401,28 @@ PT_FN bool next_bounce(PathState& ps, int32_t depth, V3& radiance) {
 // compute.wgsl:302-326.  Lambertian: normalize(norm + r).  Metal: normalize(reflect(d, norm) + r * roughness).
 // Both are computed as normalize(base + r * scale) with scale = 1 for lambertian, which is the same
 // value (r * 1.0f == r exactly).
+// `r` is the rand_in_sphere point of this bounce; the kernels draw it in separately scheduled
+// single-try steps (the only random numbers an opaque bounce consumes, so the order is unchanged).
 template <class Mem>
-PT_FN bool scatter_opaque(const Mem& mem, const SceneLayout& L, const Hit& hit, uint32_t mbits, PathState& ps,
-                          int32_t depth, V3& radiance) {
+PT_FN bool scatter_opaque_with(const Mem& mem, const SceneLayout& L, const Hit& hit, uint32_t mbits, V3 r,
+                               PathState& ps, int32_t depth, V3& radiance) {
     V3 pos, norm;
     hit_frame(mem, L, hit, ps, pos, norm);
     const bool metal = (mbits & 7u) == MAT_METAL;
     f4 m = mem.template load<f4>((metal ? L.off_metals : L.off_lambertians) + (mbits >> 3) * 16u);
     V3 base = metal ? reflect3(ps.d, norm) : norm;
     float scale = metal ? m.w : 1.0f;
-    V3 dir = normalize3(base + rand_in_sphere(ps.rng) * scale);
+    V3 dir = normalize3(base + r * scale);
     ps.o = pos + norm * 0.001f;
     ps.d = dir;
     ps.colour = ps.colour * mk(m.x, m.y, m.z);
     return next_bounce(ps, depth, radiance);
+}
+template <class Mem>
+PT_FN bool scatter_opaque(const Mem& mem, const SceneLayout& L, const Hit& hit, uint32_t mbits, PathState& ps,
+                          int32_t depth, V3& radiance) {
+    V3 r = rand_in_sphere(ps.rng);
+    return scatter_opaque_with(mem, L, hit, mbits, r, ps, depth, radiance);
 }
 
 // compute.wgsl:328-355
@@ -452,6 +469,17 @@ PT_FN bool scatter(const Mem& mem, const SceneLayout& L, const Hit& hit, PathSta
     if (cls == SC_GLASS) return scatter_glass(mem, L, hit, mbits, ps, depth, glass_always_draws, radiance);
     radiance = scatter_terminal(mem, L, mbits, ps);
     return true;
+}
+
+// n / d and n % d for n, d < 2^24 with inv = 1.0f / d: float quotient, then one step of exact
+// integer correction either way (the float product is within one of the true quotient).
+PT_FN void divmod24(uint32_t n, uint32_t d, float inv, uint32_t& q, uint32_t& r) {
+    uint32_t qq = (uint32_t)((float)n * inv);
+    int32_t rr = (int32_t)(n - qq * d);
+    if (rr < 0) qq -= 1u, rr += (int32_t)d;
+    if (rr >= (int32_t)d) qq += 1u, rr -= (int32_t)d;
+    q = qq;
+    r = (uint32_t)rr;
 }
 
 // 8x8 pixel tiles: work unit u of a frame covers tile (u % tiles_x, u / tiles_x); slot in [0,64).

@@ -34,11 +34,15 @@ for name, v in variants.items():
         if not ok:
             sys.exit(1)
 W, H, F = int(os.environ.get("AB_W", 1920)), int(os.environ.get("AB_H", 1080)), int(os.environ.get("AB_F", 64))
-r = pa.Renderer(sc, pa.Settings(1, 50), W, H)
+rs = {}
+for name, v in variants.items():   # one renderer per variant: scene-build switches apply at creation
+    setenv(v)
+    rs[name] = pa.Renderer(sc, pa.Settings(1, 50), W, H)
 res = {n: [] for n in variants}
 for rnd in range(int(os.environ.get("AB_ROUNDS", 5))):
     for name, v in variants.items():
         setenv(v)
+        r = rs[name]
         r.clear()
         r.render(F)
         s = r.stats()
