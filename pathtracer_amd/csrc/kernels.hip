@@ -350,11 +350,6 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (slot == k && type != MAT_UNKNOWN) ? 1u : 0u;
             }
         }
-        // ---- paths that end here
-        if (wants(w.cur == LANE_TERMINAL, PH_TERMINAL)) {
-            ran = true;
-            if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
-        }
         // ---- lambertian / metal
         if (wants(w.cur == LANE_OPAQUE, PH_OPAQUE)) {
             ran = true;
@@ -385,9 +380,12 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 }
             }
         }
-        // ---- idle lanes: take consecutive path ids from the wave's chunk, then start a sample
-        if (wants(w.cur == LANE_IDLE, PH_IDLE)) {
+        // ---- restart: close the paths that end at this hit / miss, hand consecutive path ids from the
+        // wave's chunk to lanes without a path, start the next sample.  One step on purpose: every
+        // path needs both halves exactly once, and a separate state would only thin out the others.
+        if (wants(w.cur == LANE_IDLE || w.cur == LANE_TERMINAL, PH_IDLE)) {
             ran = true;
+            if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
             unsigned long long m = __ballot(w.cur == LANE_IDLE && !have_path);
             while (m) {
                 if (next == end) {
