@@ -5,6 +5,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <queue>
+#include <utility>
+#include <vector>
 
 namespace pt {
 namespace {
@@ -427,6 +430,53 @@ bool build_sah(const Sphere32* spheres, uint32_t n, Bvh2& out, std::string& err)
         return false;
     }
     return true;
+}
+
+void order_top_first(Bvh2& bvh, uint32_t k_top) {
+    const uint32_t n = (uint32_t)bvh.nodes.size();
+    if (n < 3) return;
+    auto area = [&](uint32_t i) {  // surface area of the node's own box = union of its child boxes
+        const Node64& nd = bvh.nodes[i];
+        const float lo[3] = {std::min(nd.q0.x, nd.q1.z), std::min(nd.q0.y, nd.q1.w), std::min(nd.q0.z, nd.q2.x)};
+        const float hi[3] = {std::max(nd.q0.w, nd.q2.y), std::max(nd.q1.x, nd.q2.z), std::max(nd.q1.y, nd.q2.w)};
+        const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    std::vector<uint32_t> old_of_new;
+    old_of_new.reserve(n);
+    std::priority_queue<std::pair<float, uint32_t>> open;
+    open.push({area(0), 0u});
+    while (!open.empty() && old_of_new.size() < k_top) {
+        const uint32_t i = open.top().second;
+        open.pop();
+        old_of_new.push_back(i);
+        const int32_t c[2] = {bvh.nodes[i].child0, bvh.nodes[i].child1};
+        for (int k = 0; k < 2; k++)
+            if (c[k] >= 0) open.push({area((uint32_t)c[k]), (uint32_t)c[k]});
+    }
+    std::vector<uint32_t> todo;
+    while (!open.empty()) {  // roots of the subtrees below the top, largest first
+        std::vector<uint32_t> stack{open.top().second};
+        open.pop();
+        while (!stack.empty()) {
+            const uint32_t i = stack.back();
+            stack.pop_back();
+            old_of_new.push_back(i);
+            const Node64& nd = bvh.nodes[i];
+            if (nd.child1 >= 0) stack.push_back((uint32_t)nd.child1);
+            if (nd.child0 >= 0) stack.push_back((uint32_t)nd.child0);
+        }
+    }
+    std::vector<uint32_t> new_of_old(n);
+    for (uint32_t k = 0; k < n; k++) new_of_old[old_of_new[k]] = k;
+    std::vector<Node64> out(n);
+    for (uint32_t k = 0; k < n; k++) {
+        Node64 nd = bvh.nodes[old_of_new[k]];
+        if (nd.child0 >= 0) nd.child0 = (int32_t)new_of_old[(uint32_t)nd.child0];
+        if (nd.child1 >= 0) nd.child1 = (int32_t)new_of_old[(uint32_t)nd.child1];
+        out[k] = nd;
+    }
+    bvh.nodes.swap(out);
 }
 
 }  // namespace pt

@@ -19,6 +19,11 @@ struct Bvh2 {
     uint32_t max_depth = 0;       // interior nodes on the longest root-to-leaf chain
 };
 
+// Renumbers the interior nodes: the first min(k_top, n) indices go to the nodes with the largest
+// boxes, parents before children (every prefix is a connected top of the tree); the rest follow in
+// depth-first order.  The root stays node 0; leaf links and the sphere order are unchanged.
+void order_top_first(Bvh2& bvh, uint32_t k_top);
+
 // swap_mode: 0 never swap children, 1 always, 2 one xorshift32 bit per 4+-sphere node (post-order,
 // where the reference calls rand::random(), bvh.rs:107).  Returns false when n < 2 (the reference
 // panics, bvh.rs:61-62) or a position is NaN (partial_cmp().unwrap() panics, bvh.rs:91-95).

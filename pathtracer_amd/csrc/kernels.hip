@@ -46,6 +46,31 @@ struct LdsMem {
             return __builtin_bit_cast(T, v);
         }
     }
+    __device__ __forceinline__ void node64(uint32_t off, f4& q0, f4& q1, f4& q2, u2& ch) const {
+        q0 = load<f4>(off), q1 = load<f4>(off + 16), q2 = load<f4>(off + 32), ch = load<u2>(off + 48);
+    }
+    __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
+};
+// Scene blob in global memory with the first `lds_node_bytes` of the node array (the top of the
+// tree, see order_top_first) also staged in LDS.  Random record fetches from LDS sustain more than
+// twice the rate of fetches that hit in the vector L1, and the two pipes work side by side.
+struct HybridMem {
+    const char* base;
+    uint32_t lds_base;
+    uint32_t lds_node_bytes;
+    template <class T>
+    __device__ __forceinline__ T load(uint32_t off) const {
+        return *reinterpret_cast<const T*>(base + off);
+    }
+    __device__ __forceinline__ void node64(uint32_t off, f4& q0, f4& q1, f4& q2, u2& ch) const {
+        if (off < lds_node_bytes) {
+            LdsMem l{lds_base};
+            q0 = l.load<f4>(off), q1 = l.load<f4>(off + 16), q2 = l.load<f4>(off + 32), ch = l.load<u2>(off + 48);
+        } else {
+            q0 = load<f4>(off), q1 = load<f4>(off + 16), q2 = load<f4>(off + 32), ch = load<u2>(off + 48);
+        }
+    }
+    __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
 // Per-lane traversal stack in LDS, entry-major so that lane l always hits bank l % 64.
 template <int BLK>
@@ -56,6 +81,24 @@ struct LdsStack {
     }
     __device__ __forceinline__ int32_t pop(int sp) const {
         return *reinterpret_cast<const PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLK * 4u));
+    }
+};
+
+// The same stack with only its first `lds_entries` entries in LDS; deeper entries (rare: one per
+// pending far child beyond that depth) go to a per-lane area in global memory.  Keeps the LDS cost of
+// a deep tree's stacks bounded, which is what leaves room for the node prefix.
+template <int BLK>
+struct SpillStack {
+    uint32_t base;        // byte address of this lane's entry 0 in LDS
+    int32_t* spill;       // this lane's entry `lds_entries`, stride BLK
+    int32_t lds_entries;
+    __device__ __forceinline__ void push(int sp, int32_t v) const {
+        if (sp < lds_entries) *reinterpret_cast<PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLK * 4u)) = v;
+        else spill[(size_t)(sp - lds_entries) * BLK] = v;
+    }
+    __device__ __forceinline__ int32_t pop(int sp) const {
+        if (sp < lds_entries) return *reinterpret_cast<const PT_LDS(int32_t)*>(base + (uint32_t)sp * (BLK * 4u));
+        return spill[(size_t)(sp - lds_entries) * BLK];
     }
 };
 
@@ -78,6 +121,10 @@ struct RenderParams {
                       // terminal, opaque, glass, idle
     float inv_tiles_x, inv_tiles_per_frame;
     uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
+    // SCENE_GLOBAL only: scene_lds_bytes is the node prefix kept in LDS, the stack keeps
+    // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
+    int32_t* stack_spill;
+    uint32_t stack_lds_entries, stack_spill_entries;
 };
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
@@ -94,24 +141,33 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
-template <bool LDS_SCENE, bool COUNT, int BLK>
+// SCENE: where the scene blob is read from and which node format it holds.
+enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2 };
+
+template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
+    constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
-    if (LDS_SCENE) {
-        const f4* src = reinterpret_cast<const f4*>(P.scene);
+    {   // the whole blob (LDS scenes) or the node prefix (global scenes)
+        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+        const w4* src = reinterpret_cast<const w4*>(P.scene);
         for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
-        {
-            typedef uint32_t w4 __attribute__((ext_vector_type(4)));
-            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = reinterpret_cast<const w4*>(src)[i];
-        }
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
         __syncthreads();
     }
-    using Mem = typename std::conditional<LDS_SCENE, LdsMem, PtrMem>::type;
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, HybridMem>::type;
+    using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
     Mem mem;
-    if constexpr (LDS_SCENE) mem.base = lds0;
-    else mem.base = P.scene;
-    LdsStack<BLK> stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
+    Stack stack;
+    stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
+    if constexpr (LDS_SCENE) {
+        mem.base = lds0;
+    } else {
+        mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
+        stack.spill = P.stack_spill + (size_t)blockIdx.x * P.stack_spill_entries * BLK + threadIdx.x;
+        stack.lds_entries = (int32_t)P.stack_lds_entries;
+    }
 
     const CameraRegs cam = load_camera(P.cam);
     const float fw = (float)P.width, fh = (float)P.height;
@@ -187,7 +243,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
         // ---- extend + scatter
         if (alive) {
             Hit hit;
-            closest_hit<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
+            closest_hit<Mem, Stack, COUNT, HALF>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
             nrays++;
             V3 radiance;
             uint32_t mat;
@@ -246,22 +302,30 @@ constexpr int32_t LANE_OPAQUE = INT32_MIN + 4;
 constexpr int32_t LANE_GLASS = INT32_MIN + 5;
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
-template <bool LDS_SCENE, bool COUNT, int BLK>
+template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams P) {
+    constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
-    if (LDS_SCENE) {
+    {   // the whole blob (LDS scenes) or the node prefix (global scenes)
         typedef uint32_t w4 __attribute__((ext_vector_type(4)));
         const w4* src = reinterpret_cast<const w4*>(P.scene);
         for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
             *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
         __syncthreads();
     }
-    using Mem = typename std::conditional<LDS_SCENE, LdsMem, PtrMem>::type;
+    using Mem = typename std::conditional<LDS_SCENE, LdsMem, HybridMem>::type;
+    using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
     Mem mem;
-    if constexpr (LDS_SCENE) mem.base = lds0;
-    else mem.base = P.scene;
-    LdsStack<BLK> stack{lds0 + P.scene_lds_bytes + threadIdx.x * 4u};
+    Stack stack;
+    stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
+    if constexpr (LDS_SCENE) {
+        mem.base = lds0;
+    } else {
+        mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
+        stack.spill = P.stack_spill + (size_t)blockIdx.x * P.stack_spill_entries * BLK + threadIdx.x;
+        stack.lds_entries = (int32_t)P.stack_lds_entries;
+    }
 
     const CameraRegs cam = load_camera(P.cam);
     const float fw = (float)P.width, fh = (float)P.height;
@@ -273,7 +337,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     ps.rng = 1u;
     ps.bounce = 0;
     Walk w;
-    walk_begin(w, ps.o, mk(1.0f, 1.0f, 1.0f));
+    walk_begin<HALF>(w, P.L, ps.o, mk(1.0f, 1.0f, 1.0f));
     w.cur = LANE_IDLE;
     uint32_t mbits = 0;  // material word of the hit, valid in the scatter states
     V3 final_colour = mk(0.0f, 0.0f, 0.0f);
@@ -325,7 +389,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         if (wants(walk_is_node(w.cur), PH_NODE)) {
             ran = true;
             for (;;) {
-                if (walk_is_node(w.cur)) walk_node<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, w, cnt);
+                if (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT, HALF>(mem, P.L, stack, w, cnt);
                 const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_node(w.cur)));
                 if (n < P.thr[PH_NODE]) break;
                 if (COUNT) ph_exec[PH_NODE]++, ph_lanes[PH_NODE] += n;
@@ -334,7 +398,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         // ---- leaves
         if (wants(walk_is_leaf(w.cur), PH_LEAF)) {
             ran = true;
-            if (walk_is_leaf(w.cur)) walk_leaf<Mem, LdsStack<BLK>, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+            if (walk_is_leaf(w.cur)) walk_leaf<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
         }
         // ---- finished walks: fetch the material word and sort the lane into its scatter class
         if (w.cur == WALK_FINISHED) {
@@ -360,7 +424,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (scatter_opaque(mem, P.L, hit, mbits, ps, P.depth, radiance)) {
                     finish_sample(radiance);
                 } else {
-                    walk_begin(w, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
                     rays++;
                 }
             }
@@ -375,7 +439,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (scatter_glass(mem, P.L, hit, mbits, ps, P.depth, P.glass_always_draws != 0, radiance)) {
                     finish_sample(radiance);
                 } else {
-                    walk_begin(w, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
                     rays++;
                 }
             }
@@ -433,7 +497,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                     ps.o = cam.pos;
                     ps.colour = mk(1.0f, 1.0f, 1.0f);
                     ps.bounce = 0;
-                    walk_begin(w, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
                     rays++;
                 } else {
                     w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
@@ -516,6 +580,8 @@ struct Device {
     size_t frame_cap = 0;  // in f4 elements
     uint32_t* seeds = nullptr;
     size_t seeds_cap = 0;
+    int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
+    size_t spill_cap = 0;            // in entries
     uint32_t* work_counter = nullptr;  // [1]
     unsigned long long* counters = nullptr;  // [8] kernel counters + [1] rays
     std::vector<hipEvent_t> events;
@@ -578,6 +644,7 @@ void destroy(Device* d) {
     (void)hipFree(d->pixel_hash);
     (void)hipFree(d->frame_buf);
     (void)hipFree(d->seeds);
+    (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
     (void)hipFree(d->counters);
     if (d->own_stream && d->stream) (void)hipStreamDestroy(d->stream);
@@ -606,9 +673,6 @@ bool synchronize(Device* d, std::string& err) {
     return true;
 }
 
-// LDS budget per workgroup that still leaves two workgroups per CU.
-constexpr uint32_t kLdsSceneLimit = 64u * 1024u;
-
 static uint32_t stack_bytes(const SceneLayout& L, uint32_t block) { return std::max(1u, L.max_depth) * block * 4u; }
 
 bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err) {
@@ -626,8 +690,13 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
     PT_HIP(hipMemcpy(d->scene, blob, layout.total_bytes, hipMemcpyHostToDevice));
     d->layout = layout;
     d->have_scene = true;
-    d->scene_in_lds = bytes + stack_bytes(layout, 256) <= kLdsSceneLimit;
-    if (stack_bytes(layout, 256) > 160u * 1024u) {
+    d->scene_in_lds = bytes + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
+    if (layout.node_half && !d->scene_in_lds) {
+        err = "scene: half-precision nodes are only walked from LDS";
+        d->have_scene = false;
+        return false;
+    }
+    if (d->scene_in_lds && stack_bytes(layout, 256) > 160u * 1024u) {
         err = "scene: BVH too deep for the traversal stack";
         d->have_scene = false;
         return false;
@@ -693,9 +762,9 @@ bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err
     return true;
 }
 
-template <bool LDS_SCENE, bool COUNT, int BLK>
+template <int SCENE, bool COUNT, int BLK>
 static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, bool lockstep, std::string& err) {
-    auto kern = lockstep ? pt_render_kernel<LDS_SCENE, COUNT, BLK> : pt_render_sched_kernel<LDS_SCENE, COUNT, BLK>;
+    auto kern = lockstep ? pt_render_kernel<SCENE, COUNT, BLK> : pt_render_sched_kernel<SCENE, COUNT, BLK>;
     if (lds_bytes > 48u * 1024u)
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
@@ -712,12 +781,16 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
 }
 
 template <int BLK>
-static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_bytes, bool in_lds, bool count, bool lockstep,
-                              std::string& err) {
-    if (in_lds) return count ? launch_render<true, true, BLK>(d, P, lds_bytes, lockstep, err)
-                             : launch_render<true, false, BLK>(d, P, lds_bytes, lockstep, err);
-    return count ? launch_render<false, true, BLK>(d, P, lds_bytes, lockstep, err)
-                 : launch_render<false, false, BLK>(d, P, lds_bytes, lockstep, err);
+static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_bytes, int scene_mode, bool count,
+                              bool lockstep, std::string& err) {
+    if (scene_mode == SCENE_LDS_HALF)
+        return count ? launch_render<SCENE_LDS_HALF, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_LDS_HALF, false, BLK>(d, P, lds_bytes, lockstep, err);
+    if (scene_mode == SCENE_LDS)
+        return count ? launch_render<SCENE_LDS, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_LDS, false, BLK>(d, P, lds_bytes, lockstep, err);
+    return count ? launch_render<SCENE_GLOBAL, true, BLK>(d, P, lds_bytes, lockstep, err)
+                 : launch_render<SCENE_GLOBAL, false, BLK>(d, P, lds_bytes, lockstep, err);
 }
 
 static hipEvent_t get_event(Device* d, size_t i) {
@@ -810,22 +883,60 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
             for (int k = 0; k < 6; k++) P.thr[k] = t[k] < 1 ? 1 : (t[k] > 64 ? 64 : t[k]);
     }
     const bool in_lds = d->scene_in_lds;
-    P.scene_lds_bytes = in_lds ? (uint32_t)(((size_t)d->layout.total_bytes + 15u) & ~(size_t)15u) : 0u;
-    // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
-    // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
-    // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
+    const int scene_mode = in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
     const size_t lds_cu = 160u * 1024u;
-    auto waves_per_cu = [&](uint32_t blk) {
-        size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk);
-        size_t blocks = per_block ? lds_cu / per_block : 8;
-        return std::min<size_t>(blocks * (blk / 64), 24);  // 24: the register budget of these kernels
+    uint32_t block, lds_bytes;
+    auto env_int = [](const char* name, long dflt) {
+        const char* e = getenv(name);
+        return e ? atol(e) : dflt;
     };
-    uint32_t block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
-    if (const char* benv = getenv("MI355PT_BLOCK")) {
-        int v = atoi(benv);
-        if (v == 256 || v == 512 || v == 1024) block = (uint32_t)v;
+    const long benv = env_int("MI355PT_BLOCK", 0);
+    if (in_lds) {
+        P.scene_lds_bytes = (uint32_t)(((size_t)d->layout.total_bytes + 15u) & ~(size_t)15u);
+        // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
+        // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
+        // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
+        auto waves_per_cu = [&](uint32_t blk) {
+            size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk);
+            size_t blocks = per_block ? lds_cu / per_block : 8;
+            return std::min<size_t>(blocks * (blk / 64), 24);  // 24: the register budget of these kernels
+        };
+        block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
+        if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
+        lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
+    } else {
+        // Scene in global memory.  LDS holds, per workgroup, the first stack entries of every lane and
+        // as much of the top of the tree as still lets 24 waves stay resident on a CU.  Measured on
+        // MI355X with 1 M spheres at 3840x2160: 6 entries + 40 KB of nodes in 512-lane workgroups
+        // 18.3 ms per 16 frames; everything in global memory 21.7 ms; a 64 KB prefix at 8 waves per CU
+        // 33 ms (occupancy matters more than the size of the prefix).
+        // MI355PT_STACK_LDS (entries) and MI355PT_NODE_CACHE_KB override the split (development).
+        block = 512u;
+        if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
+        const uint32_t depth = std::max(1u, d->layout.max_depth);
+        P.stack_lds_entries = (uint32_t)std::min<long>(depth, std::max<long>(1, env_int("MI355PT_STACK_LDS", 6)));
+        P.stack_spill_entries = std::max(1u, depth - P.stack_lds_entries);
+        const uint32_t stack_lds = P.stack_lds_entries * block * 4u;
+        const uint32_t blocks_per_cu = std::max(1u, 24u / (block / 64u));
+        const long budget = (long)(lds_cu / blocks_per_cu) - (long)stack_lds - 2048;  // LDS is granted in granules
+        long cache = env_int("MI355PT_NODE_CACHE_KB", -1) >= 0 ? env_int("MI355PT_NODE_CACHE_KB", -1) * 1024 : budget;
+        cache = std::min<long>(cache, (long)lds_cu - (long)stack_lds);
+        cache = std::min<long>(cache, 4096l * (long)sizeof(Node64));  // the renumbered prefix (order_top_first)
+        cache = std::min<long>(cache, (long)d->layout.n_nodes * (long)sizeof(Node64));
+        cache = std::max<long>(cache, 0) / 64 * 64;
+        P.scene_lds_bytes = (d->layout.off_nodes == 0) ? (uint32_t)cache : 0u;
+        lds_bytes = P.scene_lds_bytes + stack_lds;
+        const size_t need_spill = (size_t)d->prop.multiProcessorCount * (2048u / block) * P.stack_spill_entries * block;
+        if (need_spill > d->spill_cap) {
+            PT_HIP(hipStreamSynchronize(d->stream));
+            (void)hipFree(d->stack_spill);
+            d->stack_spill = nullptr;
+            d->spill_cap = 0;
+            PT_HIP(hipMalloc(&d->stack_spill, need_spill * sizeof(int32_t)));
+            d->spill_cap = need_spill;
+        }
+        P.stack_spill = d->stack_spill;
     }
-    const uint32_t lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
     if (lds_bytes > lds_cu) {
         err = "render: traversal stacks do not fit in LDS (tree too deep)";
         return false;
@@ -841,9 +952,9 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
         PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
         bool ok;
-        if (block == 512) ok = launch_render_blk<512>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
-        else if (block == 1024) ok = launch_render_blk<1024>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
-        else ok = launch_render_blk<256>(d, P, lds_bytes, in_lds, cfg.count, lockstep, err);
+        if (block == 512) ok = launch_render_blk<512>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
+        else if (block == 1024) ok = launch_render_blk<1024>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
+        else ok = launch_render_blk<256>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
         if (!ok) return false;
         PT_HIP(hipEventRecord(get_event(d, ev++), d->stream));
         hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum,

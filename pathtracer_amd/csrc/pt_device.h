@@ -158,6 +158,12 @@ struct PtrMem {
     PT_FN T load(uint32_t byte_off) const {
         return *reinterpret_cast<const T*>(base + byte_off);
     }
+    // One interior node record.  A view may serve nodes from another place than the rest of the
+    // blob (the kernels keep the top of a large tree in LDS), hence the separate entry points.
+    PT_FN void node64(uint32_t off, f4& q0, f4& q1, f4& q2, u2& ch) const {
+        q0 = load<f4>(off), q1 = load<f4>(off + 16), q2 = load<f4>(off + 32), ch = load<u2>(off + 48);
+    }
+    PT_FN void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
 
 struct Hit {
@@ -205,7 +211,8 @@ constexpr int32_t WALK_FINISHED = INT32_MIN;
 PT_FN bool walk_is_node(int32_t cur) { return cur >= 0; }
 PT_FN bool walk_is_leaf(int32_t cur) { return (uint32_t)cur >= 0xC0000000u; }
 
-PT_FN void walk_begin(Walk& w, V3 o, V3 d) {
+template <bool HALF>
+PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d) {
     // Tiny direction components are clamped so no inf/NaN enters the box arithmetic; the
     // reciprocal may be approximate.  Neither reaches a pixel value: boxes only cull, and every
     // box carries the reference's 0.01 padding.
@@ -214,6 +221,7 @@ PT_FN void walk_begin(Walk& w, V3 o, V3 d) {
     if (fabsf(dc.y) < 1e-20f) dc.y = copysignf(1e-20f, dc.y);
     if (fabsf(dc.z) < 1e-20f) dc.z = copysignf(1e-20f, dc.z);
     w.inv = mk(PT_RCP(dc.x), PT_RCP(dc.y), PT_RCP(dc.z));
+    if (HALF) o = o - mk(L.box_org[0], L.box_org[1], L.box_org[2]);  // half boxes are relative to box_org
     w.ood = mk(o.x * w.inv.x, o.y * w.inv.y, o.z * w.inv.z);
     w.best_t = INFINITY;
     w.best_idx = -1;
@@ -235,18 +243,49 @@ PT_FN void walk_pop(Walk& w, Stack& stack) {
 // One interior node: both child boxes, near child first, far child pushed.  Requires a node.
 // (A straight-line variant with selects, an unconditional far-child store and an up-front pop was
 // measured 9 % slower: the step is bound by vector instruction issue, and the branches skip work.)
-template <class Mem, class Stack, bool COUNT>
+// binary16 -> binary32 of the low / high half of a word.  On the device the conversion folds into
+// the consuming FMA (v_fma_mix_f32), so half boxes cost no extra instructions.
+inline float half_bits_to_float(uint32_t h) {  // host-side decoder (exact)
+    const uint32_t e = (h >> 10) & 31u, m = h & 1023u;
+    float v;
+    if (e == 0) v = ldexpf((float)m, -24);
+    else if (e == 31) v = m ? NAN : INFINITY;
+    else v = ldexpf((float)(m | 1024u), (int)e - 25);
+    return (h & 0x8000u) ? -v : v;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef _Float16 pt_half2 __attribute__((ext_vector_type(2)));
+PT_FN float half_lo(uint32_t u) { return (float)__builtin_bit_cast(pt_half2, u).x; }
+PT_FN float half_hi(uint32_t u) { return (float)__builtin_bit_cast(pt_half2, u).y; }
+#else
+inline float half_lo(uint32_t u) { return half_bits_to_float(u & 0xffffu); }
+inline float half_hi(uint32_t u) { return half_bits_to_float(u >> 16); }
+#endif
+
+template <class Mem, class Stack, bool COUNT, bool HALF>
 PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, Counters& cnt) {
-    uint32_t off = L.off_nodes + (uint32_t)w.cur * 64u;
-    f4 q0 = mem.template load<f4>(off);
-    f4 q1 = mem.template load<f4>(off + 16);
-    f4 q2 = mem.template load<f4>(off + 32);
-    u2 ch = mem.template load<u2>(off + 48);
-    if (COUNT) cnt.nodes++;
     float t0, t1;
-    bool h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, w.inv, w.ood, w.best_t, t0);
-    bool h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, w.inv, w.ood, w.best_t, t1);
-    int32_t c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
+    bool h0, h1;
+    int32_t c0, c1;
+    if constexpr (HALF) {
+        uint32_t off = L.off_nodes + (uint32_t)w.cur * 32u;
+        u4 a, b;
+        mem.node32(off, a, b);
+        h0 = slab(half_lo(a.x), half_hi(a.x), half_lo(a.y), half_hi(a.y), half_lo(a.z), half_hi(a.z), w.inv, w.ood,
+                  w.best_t, t0);
+        h1 = slab(half_lo(a.w), half_hi(a.w), half_lo(b.x), half_hi(b.x), half_lo(b.y), half_hi(b.y), w.inv, w.ood,
+                  w.best_t, t1);
+        c0 = (int32_t)b.z, c1 = (int32_t)b.w;
+    } else {
+        uint32_t off = L.off_nodes + (uint32_t)w.cur * 64u;
+        f4 q0, q1, q2;
+        u2 ch;
+        mem.node64(off, q0, q1, q2, ch);
+        h0 = slab(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, w.inv, w.ood, w.best_t, t0);
+        h1 = slab(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, w.inv, w.ood, w.best_t, t1);
+        c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
+    }
+    if (COUNT) cnt.nodes++;
     if (h0 && h1) {
         bool swap = t1 < t0;
         stack.push(w.sp, swap ? c0 : c1);
@@ -304,13 +343,13 @@ PT_FN void walk_leaf(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
 }
 
 // Whole query, one ray at a time.
-template <class Mem, class Stack, bool COUNT>
+template <class Mem, class Stack, bool COUNT, bool HALF>
 PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
                        Counters& cnt) {
     Walk w;
-    walk_begin(w, o, d);
+    walk_begin<HALF>(w, L, o, d);
     for (;;) {
-        while (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT>(mem, L, stack, w, cnt);
+        while (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT, HALF>(mem, L, stack, w, cnt);
         if (w.cur == WALK_FINISHED) break;
         walk_leaf<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
     }

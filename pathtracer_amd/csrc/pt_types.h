@@ -52,6 +52,9 @@ struct alignas(16) f4 {
 struct alignas(8) u2 {
     uint32_t x, y;
 };
+struct alignas(16) u4 {
+    uint32_t x, y, z, w;
+};
 
 // One interior node of the binary BVH the kernels walk: both children's boxes and both child
 // links in one 64-byte record (four 16-byte loads).
@@ -65,13 +68,25 @@ struct alignas(16) Node64 {
     uint32_t pad[2];
 };
 static_assert(sizeof(Node64) == 64, "Node64");
+// The same node with binary16 box planes, relative to SceneLayout::box_org (two 16-byte loads):
+//   h[0..11] = c0.lo.xyz, c0.hi.xyz, c1.lo.xyz, c1.hi.xyz   then child0, child1.
+// Lower planes are rounded down and upper planes up, so a half box always contains the exact one;
+// boxes only cull, which keeps every hit and every pixel value unchanged.  Used for scenes that are
+// staged in LDS, where node bytes per visit are what bounds the walk.
+struct alignas(16) Node32 {
+    uint16_t h[12];
+    int32_t child0, child1;
+};
+static_assert(sizeof(Node32) == 32, "Node32");
 constexpr int LEAF_COUNT_SHIFT = 28;
 constexpr uint32_t LEAF_FIRST_MASK = (1u << LEAF_COUNT_SHIFT) - 1u;
 constexpr int MAX_LEAF_SPHERES = 4;
 
 // Scene blob: one contiguous, 16-byte aligned allocation; offsets in bytes.
 struct SceneLayout {
-    uint32_t off_nodes, n_nodes;      // Node64[]
+    uint32_t off_nodes, n_nodes;      // Node64[] or, with node_half, Node32[]
+    uint32_t node_half;               // 1: nodes are Node32
+    float box_org[3];                 // origin the Node32 planes are relative to
     uint32_t off_spheres, n_spheres;  // f4[]  (x, y, z, rad) in leaf order
     uint32_t off_info;                // u2[]  (min(mat_type,4) | mat_index << 3, tie rank) in leaf order
     uint32_t off_lights, n_lights;    // f4[]
@@ -81,5 +96,9 @@ struct SceneLayout {
     uint32_t total_bytes;
     uint32_t max_depth;               // deepest interior-node chain; bounds the traversal stack
 };
+
+// A scene whose blob plus the traversal stacks of a 256-lane workgroup stays within this budget is
+// staged in LDS by every workgroup (two or more workgroups per CU still fit).
+constexpr uint32_t LDS_SCENE_LIMIT = 64u * 1024u;
 
 }  // namespace pt

@@ -1,9 +1,79 @@
 #include "scene_pack.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
+#include "pt_device.h"
+
 namespace pt {
+
+namespace {
+
+// Directed rounding to binary16 by search over the 31744 non-negative finite halves.
+struct HalfTable {
+    std::vector<float> v;
+    HalfTable() {
+        v.reserve(0x7c00);
+        for (uint32_t h = 0; h < 0x7c00u; h++) v.push_back(half_bits_to_float(h));
+    }
+};
+const HalfTable& half_table() {
+    static const HalfTable t;
+    return t;
+}
+uint16_t half_mag_down(double x) {  // x >= 0: largest half <= x
+    const std::vector<float>& v = half_table().v;
+    size_t i = (size_t)(std::upper_bound(v.begin(), v.end(), x, [](double a, float b) { return a < (double)b; }) -
+                        v.begin());
+    return (uint16_t)(i - 1);
+}
+uint16_t half_mag_up(double x) {  // x >= 0: smallest half >= x, +inf beyond 65504
+    const std::vector<float>& v = half_table().v;
+    size_t i = (size_t)(std::lower_bound(v.begin(), v.end(), x, [](float a, double b) { return (double)a < b; }) -
+                        v.begin());
+    return (uint16_t)i;  // v.size() == 0x7c00 is the bit pattern of +inf
+}
+uint16_t half_floor(double x) { return x >= 0.0 ? half_mag_down(x) : (uint16_t)(0x8000u | half_mag_up(-x)); }
+uint16_t half_ceil(double x) { return x >= 0.0 ? half_mag_up(x) : (uint16_t)(0x8000u | half_mag_down(-x)); }
+
+double box_area(const double lo[3], const double hi[3]) {
+    const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Node64 -> Node32 around `org`.  Returns the mean surface-area ratio half box / exact box over all
+// child boxes (infinity when a plane leaves the binary16 range).
+double to_half_nodes(const std::vector<Node64>& in, const float org[3], std::vector<Node32>& out) {
+    out.resize(in.size());
+    double ratio_sum = 0.0;
+    for (size_t i = 0; i < in.size(); i++) {
+        const Node64& n = in[i];
+        const float b[12] = {n.q0.x, n.q0.y, n.q0.z, n.q0.w, n.q1.x, n.q1.y,
+                             n.q1.z, n.q1.w, n.q2.x, n.q2.y, n.q2.z, n.q2.w};
+        Node32& o = out[i];
+        for (int c = 0; c < 2; c++) {
+            double lo[3], hi[3], hlo[3], hhi[3];
+            for (int k = 0; k < 3; k++) {
+                lo[k] = (double)b[c * 6 + k] - (double)org[k];
+                hi[k] = (double)b[c * 6 + 3 + k] - (double)org[k];
+                const uint16_t l = half_floor(lo[k]), h = half_ceil(hi[k]);
+                o.h[c * 6 + k] = l;
+                o.h[c * 6 + 3 + k] = h;
+                hlo[k] = (double)half_bits_to_float(l);
+                hhi[k] = (double)half_bits_to_float(h);
+            }
+            const double exact = box_area(lo, hi);
+            ratio_sum += exact > 0.0 ? box_area(hlo, hhi) / exact : 1.0;
+        }
+        o.child0 = n.child0;
+        o.child1 = n.child1;
+    }
+    return in.empty() ? 1.0 : ratio_sum / (2.0 * (double)in.size());
+}
+
+}  // namespace
 
 bool validate_scene(const SceneArrays& a, std::string& err) {
     if (a.n_spheres < 2) {
@@ -69,10 +139,38 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     }
 
     auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
-    size_t off = 0;
+    const size_t rest_bytes = align16((size_t)n * sizeof(f4)) + align16((size_t)n * sizeof(u2)) +
+                              align16(a.n_lights * 16) + align16(a.n_lambertians * 16) + align16(a.n_metals * 16) +
+                              align16(a.n_glass * 4);
+    const size_t stack256 = (size_t)std::max(1u, bvh.max_depth) * 256u * 4u;
+    // Half-precision boxes for a scene that fits the LDS budget only with them (a walk over LDS
+    // sustains several times the record rate of one over the L1/L2 caches), provided rounding the
+    // planes outwards inflates the boxes by less than 10 % on average.  A scene that fits with full
+    // floats keeps them: the mixed-precision FMA issues slower than the plain one.
+    // MI355PT_NODES=float|half overrides the choice (development switch).
+    std::vector<Node32> half_nodes;
     L = SceneLayout{};
+    const char* nenv = getenv("MI355PT_NODES");
+    const bool force_half = nenv && strcmp(nenv, "half") == 0, force_float = nenv && strcmp(nenv, "float") == 0;
+    const bool lds_with_float = bvh.nodes.size() * sizeof(Node64) + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
+    const bool lds_with_half = bvh.nodes.size() * sizeof(Node32) + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
+    if (lds_with_half && !force_float && (!lds_with_float || force_half)) {
+        std::vector<float> axis(n);
+        for (int k = 0; k < 3; k++) {  // origin: median sphere centre, where the detail is
+            for (uint32_t i = 0; i < n; i++) axis[i] = a.spheres[i].pos[k];
+            std::nth_element(axis.begin(), axis.begin() + n / 2, axis.end());
+            L.box_org[k] = axis[n / 2];
+        }
+        const double inflation = to_half_nodes(bvh.nodes, L.box_org, half_nodes);
+        L.node_half = (std::isfinite(inflation) && (inflation <= 1.10 || force_half)) ? 1u : 0u;
+        if (!L.node_half) L.box_org[0] = L.box_org[1] = L.box_org[2] = 0.0f;
+    }
+    // A tree that stays in global memory is renumbered so that any prefix of the node array is the
+    // most frequently visited top of the tree; the kernels keep such a prefix in LDS.
+    if (!lds_with_float && !L.node_half) order_top_first(bvh, 4096);
+    size_t off = 0;
     L.off_nodes = (uint32_t)off, L.n_nodes = (uint32_t)bvh.nodes.size();
-    off = align16(off + bvh.nodes.size() * sizeof(Node64));
+    off = align16(off + bvh.nodes.size() * (L.node_half ? sizeof(Node32) : sizeof(Node64)));
     L.off_spheres = (uint32_t)off, L.n_spheres = n;
     off = align16(off + (size_t)n * sizeof(f4));
     L.off_info = (uint32_t)off;
@@ -92,7 +190,8 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     L.total_bytes = (uint32_t)off;
     L.max_depth = bvh.max_depth;
     blob.assign(off, 0);
-    memcpy(blob.data() + L.off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64));
+    if (L.node_half) memcpy(blob.data() + L.off_nodes, half_nodes.data(), half_nodes.size() * sizeof(Node32));
+    else memcpy(blob.data() + L.off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64));
     f4* sp = reinterpret_cast<f4*>(blob.data() + L.off_spheres);
     u2* info = reinterpret_cast<u2*>(blob.data() + L.off_info);
     for (uint32_t i = 0; i < n; i++) {

@@ -71,7 +71,7 @@ def emul():
         seeds = np.ascontiguousarray(seeds, np.uint32)
         cam = np.ascontiguousarray(cam, np.float32)
         cnt = (C.c_uint64 * 10)()
-        info = (C.c_uint32 * 3)()
+        info = (C.c_uint32 * 4)()
         x0, x1, y0, y1 = crop if crop else (0, W, 0, H)
         rn = ref_nodes.ctypes.data if ref_nodes is not None else None
         nrn = len(ref_nodes) if ref_nodes is not None else 0

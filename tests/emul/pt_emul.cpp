@@ -42,7 +42,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     SceneLayout L;
     Bvh2 bvh;
     if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) return -1;
-    if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes;
+    if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes, bvh_info[3] = L.node_half;
     PtrMem mem{blob.data()};
     Camera64 cam64v;
     memcpy(&cam64v, cam64, 64);
@@ -68,7 +68,8 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                         Hit hit;
                         HostStack st;
                         cnt = Counters{0, 0, 0};
-                        closest_hit<PtrMem, HostStack, true>(mem, L, st, ps.o, ps.d, hit, cnt);
+                        if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
+                        else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;
                         V3 radiance;
                         uint32_t mat;

@@ -1,5 +1,6 @@
 """A/B timing of kernel variants in one process, interleaved rounds (development aid; run via gpurun).
-usage: python tools/ab.py [name=ENV1=val;ENV2=val ...]"""
+usage: python tools/ab.py [name=ENV1=val;ENV2=val ...]
+env: AB_SCENE=file.ron | AB_SPHERES=n (synthetic plane), AB_W, AB_H, AB_F (frames per launch), AB_ROUNDS"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -19,9 +20,19 @@ def setenv(v):
         os.environ.pop(k, None)
     os.environ.update(v)
 
-scene_path = os.environ.get("AB_SCENE", "fixtures/scene1.ron")
-sc = pa.load_ron_scene(scene_path)
-osc = orc.Scene.from_ron(scene_path)
+import numpy as np
+if os.environ.get("AB_SPHERES"):
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(int(os.environ["AB_SPHERES"]))
+    cam = sc.camera
+    osc = orc.Scene({"camera": (np.array(cam.pos, np.float32), np.float32(cam.yaw), np.float32(cam.pitch),
+                                np.float32(cam.vfov)),
+                     "spheres": sc.spheres, "lights": sc.lights, "lambertians": sc.lambertians,
+                     "metals": sc.metals, "glass": sc.glass})
+else:
+    scene_path = os.environ.get("AB_SCENE", "fixtures/scene1.ron")
+    sc = pa.load_ron_scene(scene_path)
+    osc = orc.Scene.from_ron(scene_path)
 # parity first (small)
 W, H, seeds = 160, 90, [11, 22, 33]
 ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
@@ -29,9 +40,9 @@ for name, v in variants.items():
     setenv(v)
     with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
         r.render(seeds=seeds)
-        ok = np.array_equal(r.read_accum().view(np.uint32), ref.view(np.uint32))
-        print(f"parity {name}: {'bit-identical' if ok else 'MISMATCH'} rays {r.stats()['rays']} vs {st['rays']}", flush=True)
-        if not ok:
+        bad = int((r.read_accum().view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
+        print(f"parity {name}: {'bit-identical' if bad == 0 else f'{bad} of {W*H} pixels differ'} rays {r.stats()['rays']} vs {st['rays']}", flush=True)
+        if bad > W * H // 1000:   # the stated bound on branch flips; scenes of the reference's scale are bit-identical
             sys.exit(1)
 W, H, F = int(os.environ.get("AB_W", 1920)), int(os.environ.get("AB_H", 1080)), int(os.environ.get("AB_F", 64))
 rs = {}
