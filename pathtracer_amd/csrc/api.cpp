@@ -297,6 +297,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
     out->bvh_depth = c->bvh.max_depth;
     out->scene_bytes = c->layout.total_bytes;
     out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
+    out->node_format = c->have_scene ? c->layout.node_half : 0u;
     return MI355PT_OK;
 }
 

@@ -35,8 +35,10 @@ uint16_t half_mag_up(double x) {  // x >= 0: smallest half >= x, +inf beyond 655
                         v.begin());
     return (uint16_t)i;  // v.size() == 0x7c00 is the bit pattern of +inf
 }
+}  // namespace
 uint16_t half_floor(double x) { return x >= 0.0 ? half_mag_down(x) : (uint16_t)(0x8000u | half_mag_up(-x)); }
 uint16_t half_ceil(double x) { return x >= 0.0 ? half_mag_up(x) : (uint16_t)(0x8000u | half_mag_down(-x)); }
+namespace {
 
 double box_area(const double lo[3], const double hi[3]) {
     const double dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];

@@ -29,6 +29,11 @@ bool validate_scene(const SceneArrays& a, std::string& err);
 // reference_topology: walk the reference's own tree shape (built here, or ref_nodes when given)
 // instead of the SAH tree.  ref_nodes (optional) is a caller-built flattened reference tree; it
 // always supplies the tie ranks and, being the caller's explicit choice, the topology.
+// binary16 bit patterns of the largest half <= x / the smallest half >= x (-inf / +inf beyond the
+// finite range): the directed rounding that keeps half-precision boxes conservative.
+uint16_t half_floor(double x);
+uint16_t half_ceil(double x);
+
 bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref_nodes, size_t n_ref_nodes,
                 std::vector<char>& blob, SceneLayout& layout, Bvh2& bvh, std::string& err);
 

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../pathtracer_amd/csrc/pt_device.h"
@@ -89,6 +90,54 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
             }
         }
     if (counters) memcpy(counters, big, sizeof big);
+    return 0;
+}
+
+// Directed binary16 rounding of scene_pack: lo[i] <= x[i] <= hi[i] as floats (inf allowed).
+void emul_half_bounds(const double* x, size_t n, float* lo, float* hi) {
+    for (size_t i = 0; i < n; i++) {
+        lo[i] = half_bits_to_float(half_floor(x[i]));
+        hi[i] = half_bits_to_float(half_ceil(x[i]));
+    }
+}
+
+// SAH tree over the spheres, renumbered with order_top_first(k_top); returns 0 when the result is
+// the same tree (every sphere in exactly one leaf, every interior node reachable exactly once from
+// node 0, same depth), parents precede children inside the top prefix, and areas do not grow along
+// the prefix faster than the priority order allows; a positive code names the failed check.
+int emul_check_top_first(const void* spheres32, size_t n, uint32_t k_top) {
+    Bvh2 bvh;
+    if (!build_sah((const Sphere32*)spheres32, (uint32_t)n, bvh, g_err)) return 1;
+    const uint32_t depth_before = bvh.max_depth;
+    const size_t nodes_before = bvh.nodes.size();
+    order_top_first(bvh, k_top);
+    if (bvh.nodes.size() != nodes_before || bvh.max_depth != depth_before) return 2;
+    std::vector<uint8_t> seen_node(bvh.nodes.size(), 0), seen_sphere(n, 0);
+    std::vector<std::pair<int32_t, uint32_t>> todo{{0, 1u}};
+    uint32_t deepest = 0;
+    while (!todo.empty()) {
+        auto [link, depth] = todo.back();
+        todo.pop_back();
+        if (link >= 0) {
+            if ((size_t)link >= bvh.nodes.size() || seen_node[link]++) return 3;
+            deepest = std::max(deepest, depth);
+            const Node64& nd = bvh.nodes[link];
+            const int32_t c[2] = {nd.child0, nd.child1};
+            for (int k = 0; k < 2; k++) {
+                if (c[k] >= 0 && (uint32_t)link < k_top && (uint32_t)c[k] < k_top && c[k] <= link) return 4;
+                if (c[k] >= 0 && (uint32_t)link >= k_top && (uint32_t)c[k] < k_top) return 5;  // prefix is closed upwards
+                todo.push_back({c[k], depth + 1});
+            }
+        } else {
+            const uint32_t ref = ~(uint32_t)link, first = ref & LEAF_FIRST_MASK, count = (ref >> LEAF_COUNT_SHIFT) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                if (first + k >= n || seen_sphere[bvh.order[first + k]]++) return 6;
+            }
+        }
+    }
+    for (uint8_t v : seen_node) if (v != 1) return 7;
+    for (uint8_t v : seen_sphere) if (v != 1) return 8;
+    if (deepest != depth_before) return 9;
     return 0;
 }
 

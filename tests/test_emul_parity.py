@@ -143,3 +143,74 @@ def test_sah_tree_is_shallower_in_work_than_reference_tree(emul, orc, pa):
     _, c_ref, i_ref = emul.render(sc, cam, W, H, SEEDS[:1], ref_topo=1)
     assert i_ref[0] == 319 and i_ref[1] == 9          # 2n-1 nodes -> n-1 interior, balanced depth
     assert c_sah["nodes"] < c_ref["nodes"]
+
+
+def test_half_rounding_is_directed(emul):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.normal(0, s, 2000) for s in (1e-6, 1e-3, 1.0, 30.0, 3000.0, 1e5)] +
+                        [np.array([0.0, -0.0, 65504.0, -65504.0, 65505.0, -65505.0, 1e9, -1e9, 2.0 ** -24, -2.0 ** -24,
+                                   2.0 ** -25, 6.1e-5, 1.0, -1.0, 0.333251953125, 1000.5, -2000.0])])
+    lo = np.zeros(len(xs), np.float32)
+    hi = np.zeros(len(xs), np.float32)
+    emul.emul_half_bounds(xs.ctypes.data_as(C.c_void_p), C.c_size_t(len(xs)), lo.ctypes.data_as(C.c_void_p),
+                          hi.ctypes.data_as(C.c_void_p))
+    assert np.all(lo.astype(np.float64) <= xs) and np.all(xs <= hi.astype(np.float64))
+    # tight: both bounds are neighbouring binary16 values (or equal when x is one)
+    with np.errstate(over="ignore"):
+        as_half = xs.astype(np.float16).astype(np.float64)      # round to nearest
+    exact = as_half == xs
+    assert np.all(lo[exact] == hi[exact])
+    fin = np.isfinite(lo) & np.isfinite(hi) & ~exact
+    lo16, hi16 = lo[fin].astype(np.float16), hi[fin].astype(np.float16)
+    assert np.all(lo16.astype(np.float32) == lo[fin]) and np.all(hi16.astype(np.float32) == hi[fin])
+    assert np.all(np.nextafter(lo16, np.float16(np.inf)) == hi16)
+    big = np.abs(xs) > 65504
+    assert np.all(np.isinf(hi[big & (xs > 0)])) and np.all(lo[big & (xs > 0)] == 65504)
+    assert np.all(np.isinf(lo[big & (xs < 0)])) and np.all(hi[big & (xs < 0)] == -65504)
+
+
+def test_half_precision_nodes_do_not_change_a_bit(emul, orc, pa, monkeypatch):
+    # boxes only cull: conservative binary16 planes must give the very same image
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    osc = oracle_scene(orc, sc)
+    W, H = 96, 54
+    cam = osc.camera(W, H)
+    ref, st = orc.render(osc, cam, W, H, SEEDS, threads=4)
+    monkeypatch.setenv("MI355PT_NODES", "half")
+    acc, cnt, info = emul.render(sc, cam, W, H, SEEDS)
+    assert info[3] == 1
+    assert bits_equal(ref, acc) and cnt["rays"] == st["rays"]
+    monkeypatch.setenv("MI355PT_NODES", "float")
+    acc_f, cnt_f, info_f = emul.render(sc, cam, W, H, SEEDS)
+    assert info_f[3] == 0 and bits_equal(ref, acc_f)
+    assert info[2] < info_f[2]                       # smaller blob
+    assert cnt_f["nodes"] <= cnt["nodes"] <= cnt_f["nodes"] * 1.05   # slightly looser boxes, a few more visits
+
+
+def test_half_precision_nodes_are_chosen_when_only_they_fit_lds(emul, orc, pa):
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(800)
+    osc = oracle_scene(orc, sc)
+    W, H = 160, 90
+    cam = osc.camera(W, H)
+    crop = (40, 120, 30, 70)
+    ref, st = orc.render(osc, cam, W, H, SEEDS[:2], crop=crop, threads=4)
+    acc, cnt, info = emul.render(sc, cam, W, H, SEEDS[:2], crop=crop)
+    assert info[3] == 1 and info[2] + info[1] * 1024 <= 64 * 1024
+    assert bits_equal(ref, acc)
+    # a scene with detail far from its median centre keeps float boxes (the planes would round too coarsely)
+    far = synth.plane_scene(800)
+    far.spheres["pos"][4:, 0] += np.float32(30000.0)
+    far.spheres["pos"][4:400, 0] -= np.float32(60000.0)
+    _, _, info_far = emul.render(far, cam, 16, 9, SEEDS[:1])
+    assert info_far[3] == 0
+
+
+@pytest.mark.parametrize("k_top", [1, 64, 4096, 10 ** 9])
+def test_top_first_node_order_is_the_same_tree(emul, pa, k_top):
+    import ctypes as C
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(5000)
+    rc = emul.emul_check_top_first(C.c_void_p(sc.spheres.ctypes.data), C.c_size_t(len(sc.spheres)), C.c_uint32(min(k_top, 2 ** 32 - 1)))
+    assert rc == 0

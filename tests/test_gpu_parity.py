@@ -6,6 +6,12 @@ binary32 operation per source operation on both sides (no contraction, correctly
 sqrt), and per-frame results are added in frame order, so no tolerance is needed; the fallback
 tolerance the design allows (>= 99.9 % of pixels within 1e-5 relative for one frame) is therefore
 never exercised and a single differing bit fails these tests.
+
+One exception, named in its test: the million-sphere plane.  There, ray-sphere roots of far, small
+spheres lose so many bits to cancellation that a root can be "found" for a ray that misses the
+sphere's padded box; whether such a root is ever computed depends on which boxes a walk tests, in
+the reference as much as here, so a few pixels per ten thousand (all on the horizon) depend on the
+tree.  That test uses the fallback bound: fewer than 0.1 % of pixels may differ.
 """
 import json
 import os
@@ -213,6 +219,35 @@ def test_large_scene_in_global_memory(pa, orc):
     assert gs["scene_in_lds"] == 0
     x0, x1, y0, y1 = crop
     assert bits_equal(ref[y0:y1, x0:x1], acc[y0:y1, x0:x1])
+
+
+def test_half_precision_nodes_in_lds(pa, orc):
+    # ~800 spheres fit the LDS budget only with 32-byte nodes; conservative boxes change no bit
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(800)
+    osc = oracle_scene(orc, sc)
+    W, H = 160, 90
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:3], threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, SEEDS[:3], flags=pa.FLAG_COUNT)
+    assert gs["scene_in_lds"] == 1 and gs["node_format"] == 1
+    assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
+
+
+def test_million_spheres_within_the_stated_bound(pa, orc):
+    # deep tree (spilling stack, node prefix in LDS, 68 MB blob); see the module docstring for the bound
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(1_000_000)
+    osc = oracle_scene(orc, sc)
+    W, H = 160, 90
+    seeds = [11, 22, 33]
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, seeds)
+    assert gs["scene_in_lds"] == 0 and gs["bvh_depth"] > 12
+    differ = (acc.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
+    assert differ.sum() * 1000 < W * H
+    rows = np.unique(np.argwhere(differ)[:, 0])
+    assert len(rows) <= 2                         # the horizon
+    assert abs(int(gs["rays"]) - int(st["rays"])) <= 8
 
 
 def test_validation_errors(pa):
