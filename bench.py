@@ -84,10 +84,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the library has no CPU path)")
+    # MI355PT_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks
+    # (ranks then share devices and the reduce is staged through the host); the measured path is nccl.
+    backend = os.environ.get("MI355PT_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     W, H, F = args.width, args.height, args.frames_per_step
     scene = pa.load_ron_scene(args.scene)
@@ -110,8 +118,7 @@ def main():
     for s in range(args.warmup):
         r.render(seeds=step_seeds(args.steps + s))
     if world > 1 and args.warmup:
-        warm = torch.zeros_like(acc_t)
-        dist.reduce(warm, dst=0)  # communicator set-up outside the timed region
+        parallel.reduce_accum(torch.zeros_like(acc_t), world, dst=0)  # communicator set-up outside the timed region
     r.clear()
     sync()
     t0 = time.perf_counter()
@@ -143,7 +150,8 @@ def main():
             "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, {F} frames/step x {args.steps} steps "
                                    f"per GPU, 1 spp/frame, depth 50 (BASELINE configs[1])",
                        "frames_per_gpu": F * args.steps, "paths_per_step_per_gpu": W * H * F,
-                       "parallelism": f"frame-partitioned x{world}, one RCCL sum-reduce" if world > 1 else "1 GPU",
+                       "parallelism": f"frame-partitioned x{world}, one {'RCCL' if backend == 'nccl' else backend} sum-reduce"
+                                      if world > 1 else "1 GPU",
                        "bvh": "binned SAH, 64-B two-child nodes", "scene_in_lds": bool(st["scene_in_lds"])},
             "rays_per_path": rays_all / paths_all,
             "kernel_ms_per_launch": kernel_ms,

@@ -125,6 +125,7 @@ struct RenderParams {
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
     int32_t* stack_spill;
     uint32_t stack_lds_entries, stack_spill_entries;
+    uint32_t leaf_one;  // leaf steps test one sphere per lane
 };
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
@@ -398,7 +399,16 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         // ---- leaves
         if (wants(walk_is_leaf(w.cur), PH_LEAF)) {
             ran = true;
-            if (walk_is_leaf(w.cur)) walk_leaf<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+            if (P.leaf_one) {
+                for (;;) {
+                    if (walk_is_leaf(w.cur)) walk_leaf_one<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+                    const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_leaf(w.cur)));
+                    if (n < P.thr[PH_LEAF]) break;
+                    if (COUNT) ph_exec[PH_LEAF]++, ph_lanes[PH_LEAF] += n;
+                }
+            } else {
+                if (walk_is_leaf(w.cur)) walk_leaf<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+            }
         }
         // ---- finished walks: fetch the material word and sort the lane into its scatter class
         if (w.cur == WALK_FINISHED) {
@@ -875,12 +885,17 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
     P.inv_tiles_x = 1.0f / (float)tiles_x;
     P.inv_tiles_per_frame = 1.0f / (float)tiles;
-    const uint32_t default_thr[6] = {16, 16, 24, 24, 8, 32};
+    const uint32_t default_thr[6] = {16, 8, 24, 24, 8, 32};
     for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
             for (int k = 0; k < 6; k++) P.thr[k] = t[k] < 1 ? 1 : (t[k] > 64 ? 64 : t[k]);
+    }
+    {
+        // MI355PT_LEAF=loop: a leaf step tests all spheres of the lane's leaf (development switch)
+        const char* lenv = getenv("MI355PT_LEAF");
+        P.leaf_one = (lenv && strcmp(lenv, "loop") == 0) ? 0u : 1u;
     }
     const bool in_lds = d->scene_in_lds;
     const int scene_mode = in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;

@@ -300,46 +300,61 @@ PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
     }
 }
 
-// Every sphere of the current leaf (compute.wgsl:116-135 with the running closest t), then the
-// next stack entry.  Requires a leaf.
+// One sphere against the running closest hit (compute.wgsl:116-135 with t_max = closest so far).
+template <class Mem, bool COUNT>
+PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o, V3 d, uint32_t si, Counters& cnt) {
+    f4 s = mem.template load<f4>(L.off_spheres + si * 16u);
+    if (COUNT) cnt.tests++;
+    V3 oc = o - mk(s.x, s.y, s.z);
+    float half_b = dot3(oc, d);
+    float c = dot3(oc, oc) - (s.w * s.w);
+    float disc = half_b * half_b - c;
+    if (!(disc < 0.0f)) {
+        float sq = sqrtf(disc);
+        float t = -half_b - sq;
+        bool back = false;
+        if (t < 0.0f) {
+            t = -half_b + sq;
+            back = true;
+        }
+        if (!(t < 0.0f)) {
+            bool take = t < w.best_t;
+            if (t == w.best_t && w.best_idx >= 0) {
+                uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
+                uint32_t best_rank = mem.template load<u2>(L.off_info + (uint32_t)w.best_idx * 8u).y;
+                take = rank > best_rank;
+            }
+            if (take) {
+                if (COUNT) cnt.accepted++;
+                w.best_t = t;
+                w.best_idx = (int32_t)si;
+                w.best_back = back;
+            }
+        }
+    }
+}
+
+// Every sphere of the current leaf, then the next stack entry.  Requires a leaf.
 template <class Mem, class Stack, bool COUNT>
 PT_FN void walk_leaf(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, V3 o, V3 d, Counters& cnt) {
     uint32_t ref = ~(uint32_t)w.cur;
     uint32_t first = ref & LEAF_FIRST_MASK;
     uint32_t count = (ref >> LEAF_COUNT_SHIFT) + 1u;
-    for (uint32_t k = 0; k < count; k++) {
-        uint32_t si = first + k;
-        f4 s = mem.template load<f4>(L.off_spheres + si * 16u);
-        if (COUNT) cnt.tests++;
-        V3 oc = o - mk(s.x, s.y, s.z);
-        float half_b = dot3(oc, d);
-        float c = dot3(oc, oc) - (s.w * s.w);
-        float disc = half_b * half_b - c;
-        if (!(disc < 0.0f)) {
-            float sq = sqrtf(disc);
-            float t = -half_b - sq;
-            bool back = false;
-            if (t < 0.0f) {
-                t = -half_b + sq;
-                back = true;
-            }
-            if (!(t < 0.0f)) {
-                bool take = t < w.best_t;
-                if (t == w.best_t && w.best_idx >= 0) {
-                    uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
-                    uint32_t best_rank = mem.template load<u2>(L.off_info + (uint32_t)w.best_idx * 8u).y;
-                    take = rank > best_rank;
-                }
-                if (take) {
-                    if (COUNT) cnt.accepted++;
-                    w.best_t = t;
-                    w.best_idx = (int32_t)si;
-                    w.best_back = back;
-                }
-            }
-        }
-    }
+    for (uint32_t k = 0; k < count; k++) walk_test_sphere<Mem, COUNT>(mem, L, w, o, d, first + k, cnt);
     walk_pop(w, stack);
+}
+
+// The first sphere of the current leaf only; the lane keeps the rest of the leaf as its pending
+// leaf, or takes the next stack entry after the last sphere.  Lanes of a wave then never wait for
+// the longest leaf among them.  Requires a leaf.
+template <class Mem, class Stack, bool COUNT>
+PT_FN void walk_leaf_one(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, V3 o, V3 d, Counters& cnt) {
+    uint32_t ref = ~(uint32_t)w.cur;
+    uint32_t si = ref & LEAF_FIRST_MASK;
+    uint32_t more = ref >> LEAF_COUNT_SHIFT;
+    walk_test_sphere<Mem, COUNT>(mem, L, w, o, d, si, cnt);
+    if (more) w.cur = (int32_t)~((si + 1u) | ((more - 1u) << LEAF_COUNT_SHIFT));
+    else walk_pop(w, stack);
 }
 
 // Whole query, one ray at a time.

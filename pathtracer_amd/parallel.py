@@ -37,7 +37,13 @@ def reduce_accum(tensor, world, dst=0):
     the constant alpha of the reference's texture (every rank cleared its own to 1)."""
     import torch.distributed as dist
     if world > 1:
-        dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
+        if tensor.is_cuda and dist.get_backend() == "gloo":  # gloo reduces host tensors only
+            host = tensor.cpu()
+            dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
+            if dist.get_rank() == dst:
+                tensor.copy_(host)
+        else:
+            dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
     if dist.get_rank() == dst if world > 1 else True:
         tensor[..., 3] = 1.0
     return tensor
