@@ -18,8 +18,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak), packed FMA counted as 2x2
+PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak): 256 CUs x 128 FMA lanes x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
+# rocprofv3 summary of this command (tools/profile.sh): source of roofline.traffic and of the issue-slot figure
+PROFILE = os.path.join("profiles", "r01_v3_sched", "pmc_summary.json")
+# highest sustained vector issue rate measured on MI355X (tools/micro/valu_peak, profiles/r01_micro/valu_peak.txt)
+MEASURED_VALU_ISSUE_PER_SIMD = 9.07e8   # wave-instructions / s / SIMD
 
 
 def flops_per_launch(st):
@@ -38,22 +42,17 @@ def bytes_per_launch(st):
     return st["nodes"] * 64 + st["tests"] * 16 + hits * 40
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the newest committed rocprofv3 counter passes
-    (profiles/*/pmc_summary.json, same bench command): 2 x FETCH_SIZE + WRITE_SIZE, in KiB -> bytes.
-    FETCH_SIZE under-reports wide reads by 2x on gfx950 (MI355X_MICROARCH.md, HBM section)."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for name, v in d.items():
-            c = v.get("counters_avg_per_dispatch", {})
-            if kernel_prefix in name and "false" in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-                best = (f, (2.0 * c["FETCH_SIZE"]["avg"] + c["WRITE_SIZE"]["avg"]) * 1024.0)
-    return best
+def profile_counters(kernel_prefix):
+    """Per-launch counter averages of the timed (non-counting) instance of the dominant kernel from the
+    committed rocprofv3 passes of this same command, or None."""
+    try:
+        d = json.load(open(os.path.join(ROOT, PROFILE)))
+    except Exception:
+        return None
+    for name, v in d.items():
+        if kernel_prefix in name and "false" in name:
+            return {k: c["avg"] for k, c in v.get("counters_avg_per_dispatch", {}).items()}
+    return None
 
 
 def main():
@@ -169,16 +168,27 @@ def main():
             "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None, "traffic_unit": "bytes/launch",
             "kernel": "pt_render_sched_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
             "nodes_per_ray": cs["nodes"] / cs["rays"], "sphere_tests_per_ray": cs["tests"] / cs["rays"],
-            "note": "scene (22 KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
+            "note": f"scene ({cs['scene_bytes'] / 1024:.0f} KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
                     "vector FP32 figure (equal to the FP32 MFMA peak)",
             "scene_fetch": {"bytes_per_ray": by / cs["rays"], "achieved_GBps": by / (kernel_ms * 1e-3) / 1e9,
                             "served_from": "LDS" if cs["scene_in_lds"] else "L2/HBM", "hbm_peak_GBps": PEAK_HBM_GBS},
         }
-        tr = pmc_traffic("pt_render_sched_kernel")
-        if tr and os.path.basename(args.scene) == "scene1.ron" and (W, H, F) == (1920, 1080, 64):
-            out["roofline"]["traffic"] = tr[1]
-            out["roofline"]["traffic_source"] = os.path.relpath(tr[0], ROOT)
-            out["roofline"]["hbm_GBps_from_traffic"] = tr[1] / (kernel_ms * 1e-3) / 1e9
+        pc = profile_counters("pt_render_sched_kernel")
+        if pc and os.path.basename(args.scene) == "scene1.ron" and (W, H, F) == (1920, 1080, 64):
+            # HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (FETCH_SIZE under-reports wide
+            # reads by 2x on gfx950)
+            tr = (2.0 * pc["FETCH_SIZE"] + pc["WRITE_SIZE"]) * 1024.0
+            out["roofline"]["traffic"] = tr
+            out["roofline"]["traffic_source"] = PROFILE
+            out["roofline"]["hbm_GBps_from_traffic"] = tr / (kernel_ms * 1e-3) / 1e9
+            simds = 4 * torch.cuda.get_device_properties(local_rank).multi_processor_count
+            rate = pc["SQ_INSTS_VALU"] / simds / (kernel_ms * 1e-3)
+            out["roofline"]["valu_issue"] = {
+                "wave_instr_per_launch": pc["SQ_INSTS_VALU"], "per_simd_per_s": rate,
+                "measured_peak_per_simd_per_s": MEASURED_VALU_ISSUE_PER_SIMD,
+                "frac": rate / MEASURED_VALU_ISSUE_PER_SIMD,
+                "active_lanes_per_instr": pc["SQ_THREAD_CYCLES_VALU"] / pc["SQ_INSTS_VALU"],
+            }
         # ---- converged-image parity against the reference's own render (outside the timed region)
         if not args.no_rmse and os.path.basename(args.scene) == "scene1.ron":
             try:
@@ -197,7 +207,7 @@ def main():
             from oracle import orc
             osc = orc.Scene.from_ron(args.scene)
             threads = min(16, os.cpu_count() or 1)
-            n_cpu_frames = 8
+            n_cpu_frames = 64   # the whole step-0 batch: the very work of one GPU step
             seeds = step_seeds(0)[:n_cpu_frames]
             t1 = time.perf_counter()
             _, ost = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=threads)
