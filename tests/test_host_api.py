@@ -22,6 +22,23 @@ def test_library_exports_every_declared_symbol(pa):
     assert declared == set(binding.SIGNATURES), "binding.SIGNATURES out of sync with the header"
 
 
+def test_rust_declarations_cover_the_header(pa):
+    # the -sys crate cannot be compiled here (no rustc); at least keep its names and struct fields in step
+    hdr = open(os.path.join(ROOT, "include", "mi355pt.h")).read()
+    hdr_nc = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mi355pt_[a-z0-9_]+)\s*\(", hdr_nc))
+    rs = open(os.path.join(ROOT, "bindings", "rust", "mi355pt-sys", "src", "lib.rs")).read()
+    rust_fns = set(re.findall(r"pub fn (mi355pt_[a-z0-9_]+)\s*\(", rs))
+    assert rust_fns == declared
+    stats_c = re.search(r"typedef struct mi355pt_stats \{(.*?)\} mi355pt_stats;", hdr_nc, re.S).group(1)
+    fields_c = re.findall(r"\b([a-z_]+)(?:\[\d+\])?;", stats_c)
+    stats_rs = re.search(r"pub struct mi355pt_stats \{(.*?)\n\}", rs, re.S).group(1)
+    fields_rs = re.findall(r"pub ([a-z_]+):", stats_rs)
+    assert fields_rs == fields_c
+    from pathtracer_amd import binding
+    assert [f[0] for f in binding.Stats._fields_] == fields_c
+
+
 def test_library_is_hip_only(pa):
     # the product links the HIP runtime and exposes no oracle entry points
     out = os.popen(f"readelf -d {pa.library_path()}").read()

@@ -337,6 +337,24 @@ int main(int argc, char** argv) {
                 }
                 paths.push_back(std::move(p));
             }
+    if (argc > 5 && !strcmp(argv[5], "postpone")) {
+        // optimistic model of postponed leaves: a lane holds the sphere tests of one leaf and keeps
+        // walking until it reaches the next leaf or the end (extra node visits from later pruning ignored)
+        for (auto& p : paths)
+            for (auto& sg : p) {
+                std::string out, held;
+                size_t i = 0;
+                while (i < sg.steps.size()) {
+                    if (sg.steps[i] == 'N') { out += 'N'; i++; continue; }
+                    std::string run;
+                    while (i < sg.steps.size() && sg.steps[i] == 'L') run += 'L', i++;
+                    out += held;
+                    held = run;
+                }
+                out += held;
+                sg.steps = out;
+            }
+    }
     printf("%zu paths, %zu rays (%.3f rays/path)\n", paths.size(), rays, (double)rays / paths.size());
 
     // waves take chunks of 256 consecutive paths; model a wave as running chunk after chunk
