@@ -122,7 +122,8 @@ def main():
     sync()
     t0 = time.perf_counter()
     for s in range(args.steps):
-        r.render(seeds=step_seeds(s))
+        r.render(seeds=step_seeds(s), wait=False)   # a step's accumulation overlaps the next step's path kernel
+    r.wait()
     if world > 1:
         parallel.reduce_accum(acc_t, world, dst=0)
     sync()

@@ -110,6 +110,14 @@ impl Renderer {
     pub fn render_with_seeds(&mut self, seeds: &[u32]) -> Result<()> {
         self.check(unsafe { sys::mi355pt_render(self.ctx, seeds.len() as u32, seeds.as_ptr()) })
     }
+    /// Queue frames without waiting (overlaps accumulation with the next call's path kernel); `wait`
+    /// or any reading call joins.
+    pub fn render_async(&mut self, frames: u32) -> Result<()> {
+        self.check(unsafe { sys::mi355pt_render_async(self.ctx, frames, std::ptr::null()) })
+    }
+    pub fn wait(&mut self) -> Result<()> {
+        self.check(unsafe { sys::mi355pt_wait(self.ctx) })
+    }
     /// mod.rs:246-248.
     pub fn samples(&self) -> i32 {
         unsafe { sys::mi355pt_frames(self.ctx) }

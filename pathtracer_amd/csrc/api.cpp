@@ -57,6 +57,18 @@ int fail(mi355pt_ctx* ctx, int code, const std::string& msg) {
     return code;
 }
 
+// Waits for work queued by mi355pt_render_async and folds its timings / counters into the context.
+int settle(mi355pt_ctx* c) {
+    std::string err;
+    if (!gpu::finish(c->dev, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    return MI355PT_OK;
+}
+#define SETTLE_OR_RETURN(c)              \
+    do {                                 \
+        int settle_rc_ = settle(c);      \
+        if (settle_rc_ != MI355PT_OK) return settle_rc_; \
+    } while (0)
+
 // Builds (or converts) the tree, packs the device blob and uploads it.  ref_nodes may be null.
 int install_tree(mi355pt_ctx* c, const Node48* ref_nodes, size_t n_ref_nodes) {
     SceneArrays a;
@@ -121,6 +133,7 @@ int mi355pt_create(const mi355pt_desc* desc, mi355pt_ctx** out) {
 
 void mi355pt_destroy(mi355pt_ctx* ctx) {
     if (!ctx) return;
+    (void)settle(ctx);
     gpu::destroy(ctx->dev);
     delete ctx;
 }
@@ -131,6 +144,7 @@ int mi355pt_set_scene(mi355pt_ctx* c, const void* spheres32, size_t n_spheres, c
                       const void* lambertians16, size_t n_lambertians, const void* metals16, size_t n_metals,
                       const void* glass4, size_t n_glass) {
     if (!c) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     {
         SceneArrays a;
         a.spheres = static_cast<const Sphere32*>(spheres32), a.n_spheres = n_spheres;
@@ -160,6 +174,7 @@ int mi355pt_set_bvh(mi355pt_ctx* c, const void* nodes48, size_t n_nodes) {
     if (!c) return MI355PT_ERR_ARG;
     if (c->spheres.empty()) return fail(c, MI355PT_ERR_STATE, "set_bvh: call set_scene first");
     if (!nodes48) return fail(c, MI355PT_ERR_ARG, "set_bvh: null nodes");
+    SETTLE_OR_RETURN(c);
     return install_tree(c, static_cast<const Node48*>(nodes48), n_nodes);
 }
 
@@ -199,6 +214,7 @@ int mi355pt_set_settings(mi355pt_ctx* c, int32_t samples, int32_t depth) {
 
 int mi355pt_resize(mi355pt_ctx* c, uint32_t width, uint32_t height) {
     if (!c) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     std::string err;
     if (!gpu::resize(c->dev, width, height, err)) return fail(c, MI355PT_ERR_DEVICE, err);
     c->width = width, c->height = height;
@@ -208,6 +224,7 @@ int mi355pt_resize(mi355pt_ctx* c, uint32_t width, uint32_t height) {
 
 int mi355pt_clear(mi355pt_ctx* c) {
     if (!c) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     std::string err;
     rebuild_camera(c);
     if (!gpu::clear(c->dev, err)) return fail(c, MI355PT_ERR_DEVICE, err);
@@ -218,7 +235,7 @@ int mi355pt_clear(mi355pt_ctx* c) {
     return MI355PT_OK;
 }
 
-int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
     if (!c) return MI355PT_ERR_ARG;
     if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
     if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
@@ -239,16 +256,27 @@ int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
     cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
     cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
     std::string err;
-    if (!gpu::render(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    if (!gpu::enqueue(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
     c->frames += (int32_t)n_frames;
     c->seed_index += n_frames;
     return MI355PT_OK;
+}
+
+int mi355pt_wait(mi355pt_ctx* c) {
+    if (!c) return MI355PT_ERR_ARG;
+    return settle(c);
+}
+
+int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+    int r = mi355pt_render_async(c, n_frames, seeds);
+    return r == MI355PT_OK ? mi355pt_wait(c) : r;
 }
 
 int32_t mi355pt_frames(const mi355pt_ctx* c) { return c ? c->frames : -1; }
 
 int mi355pt_read_accum(mi355pt_ctx* c, float* rgba, size_t n_floats) {
     if (!c || !rgba) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     std::string err;
     if (!gpu::read_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
     return MI355PT_OK;
@@ -256,6 +284,7 @@ int mi355pt_read_accum(mi355pt_ctx* c, float* rgba, size_t n_floats) {
 
 int mi355pt_write_accum(mi355pt_ctx* c, const float* rgba, size_t n_floats, int32_t frames) {
     if (!c || !rgba) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     std::string err;
     if (!gpu::write_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
     c->frames = frames;
@@ -267,6 +296,7 @@ int mi355pt_to_rgb8(mi355pt_ctx* c, int32_t frames, uint8_t* rgb, size_t n_bytes
     if (!c || !rgb) return MI355PT_ERR_ARG;
     if (n_bytes != (size_t)c->width * c->height * 3) return fail(c, MI355PT_ERR_ARG, "to_rgb8: n_bytes must be 3 * width * height");
     if (frames < 1) return fail(c, MI355PT_ERR_ARG, "to_rgb8: frames must be >= 1");
+    SETTLE_OR_RETURN(c);
     std::vector<float> acc((size_t)c->width * c->height * 4);
     std::string err;
     if (!gpu::read_accum(c->dev, acc.data(), acc.size(), err)) return fail(c, MI355PT_ERR_DEVICE, err);
@@ -286,6 +316,7 @@ int mi355pt_save_png(mi355pt_ctx* c, int32_t frames, const char* path) {
 
 int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
     if (!c || !out) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     memset(out, 0, sizeof *out);
     out->paths = c->stats.paths, out->rays = c->stats.rays;
     out->nodes = c->stats.nodes, out->tests = c->stats.tests, out->accepted = c->stats.accepted;
@@ -303,6 +334,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
 
 int mi355pt_accum_device_ptr(mi355pt_ctx* c, void** ptr, void** stream) {
     if (!c) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
     if (ptr) *ptr = gpu::accum_device_ptr(c->dev);
     if (stream) *stream = gpu::stream_handle(c->dev);
     return MI355PT_OK;

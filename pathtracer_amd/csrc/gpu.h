@@ -40,6 +40,13 @@ bool clear(Device* d, std::string& err);
 // Accumulates n_frames frames (seeds[f] = Globals.seed of frame f) in frame order.
 bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
             RenderStats& stats, std::string& err);
+// The same in two halves: enqueue() returns once the work is queued on the device (path kernels on the
+// render stream, frame-order accumulation on a second stream, overlapping the next batch's path kernel);
+// finish() waits for everything queued so far and folds its timings and counters into `stats`.
+// Every other entry point below expects finish() to have been called.
+bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+             RenderStats& stats, std::string& err);
+bool finish(Device* d, RenderStats& stats, std::string& err);
 bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
 void* accum_device_ptr(Device* d);

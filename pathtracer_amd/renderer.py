@@ -242,14 +242,20 @@ class Renderer:
         self._check(lib().mi355pt_resize(self._ctx, int(width), int(height)))
         self.width, self.height = int(width), int(height)
 
-    def render(self, n_frames=1, seeds=None):  # mod.rs:168-244, n_frames times
+    def render(self, n_frames=1, seeds=None, wait=True):  # mod.rs:168-244, n_frames times
+        """wait=False queues the frames and returns (mi355pt_render_async); `wait()` or any reading call
+        joins."""
         if seeds is not None:
             seeds = np.ascontiguousarray(seeds, np.uint32)
             n_frames = len(seeds)
             p = seeds.ctypes.data_as(C.POINTER(C.c_uint32))
         else:
             p = None
-        self._check(lib().mi355pt_render(self._ctx, int(n_frames), p))
+        fn = lib().mi355pt_render if wait else lib().mi355pt_render_async
+        self._check(fn(self._ctx, int(n_frames), p))
+
+    def wait(self):
+        self._check(lib().mi355pt_wait(self._ctx))
 
     def samples(self):  # mod.rs:246-248
         return int(lib().mi355pt_frames(self._ctx))

@@ -207,6 +207,28 @@ def test_frame_order_and_batching_do_not_change_bits(pa):
     assert np.all(one[..., 3] == 1.0) and np.isfinite(one).all()
 
 
+def test_queued_renders_equal_blocking_renders(pa):
+    # render_async pipelines accumulation (second stream, two frame buffers) under the next path kernel;
+    # frames must still be added in order
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    W, H = 256, 144
+    seeds = np.arange(1, 215, dtype=np.uint32) * np.uint32(2654435761)
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        r.render(seeds=seeds)
+        blocking, st_b = r.read_accum(), r.stats()
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        at = 0
+        for n in (70, 3, 64, 13, 64):
+            r.render(seeds=seeds[at:at + n], wait=False)
+            at += n
+        assert at == len(seeds) and r.samples() == len(seeds)
+        queued, st_q = r.read_accum(), r.stats()          # read_accum joins
+        r.wait()                                          # joining twice is harmless
+    assert bits_equal(blocking, queued)
+    assert st_q["rays"] == st_b["rays"] and st_q["paths"] == st_b["paths"]
+    assert st_q["launches"] == 6 and st_q["render_ms"] > 0 and st_q["resolve_ms"] > 0
+
+
 def test_large_scene_in_global_memory(pa, orc):
     # ~20k spheres: the scene blob no longer fits the LDS budget, nodes come from L2/HBM
     from pathtracer_amd import synth
