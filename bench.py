@@ -4,8 +4,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A step is one pass of the path kernel over one batch of frames (default 64 frames = 132.7 M paths per
-GPU); the default 16 steps are the 1024 frames of the headline configuration.  With N GPUs every rank
+A step is one pass of the path kernel over one batch of frames (default 256 frames = 530.8 M paths per
+GPU, one launch); 4 steps are the 1024 frames of the headline configuration, the default 16 steps render
+4096 frames.  With N GPUs every rank
 renders its own disjoint frames (weak scaling), and the accumulators are sum-reduced to rank 0 over
 RCCL inside the timed region.  Rank 0 prints one JSON line.
 """
@@ -21,7 +22,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak): 256 CUs x 128 FMA lanes x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 # rocprofv3 summary of this command (tools/profile.sh): source of roofline.traffic and of the issue-slot figure
-PROFILE = os.path.join("profiles", "r01_v3_sched", "pmc_summary.json")
+PROFILE = os.path.join("profiles", "r01_v4_256f", "pmc_summary.json")
 # highest sustained vector issue rate measured on MI355X (tools/micro/valu_peak, profiles/r01_micro/valu_peak.txt)
 MEASURED_VALU_ISSUE_PER_SIMD = 9.07e8   # wave-instructions / s / SIMD
 
@@ -60,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--frames-per-step", type=int, default=256)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "fixtures", "scene1.ron"))
@@ -175,7 +176,7 @@ def main():
                             "served_from": "LDS" if cs["scene_in_lds"] else "L2/HBM", "hbm_peak_GBps": PEAK_HBM_GBS},
         }
         pc = profile_counters("pt_render_sched_kernel")
-        if pc and os.path.basename(args.scene) == "scene1.ron" and (W, H, F) == (1920, 1080, 64):
+        if pc and os.path.basename(args.scene) == "scene1.ron" and (W, H, F) == (1920, 1080, 256):
             # HBM bytes per launch: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes (FETCH_SIZE under-reports wide
             # reads by 2x on gfx950)
             tr = (2.0 * pc["FETCH_SIZE"] + pc["WRITE_SIZE"]) * 1024.0
@@ -208,7 +209,7 @@ def main():
             from oracle import orc
             osc = orc.Scene.from_ron(args.scene)
             threads = min(16, os.cpu_count() or 1)
-            n_cpu_frames = 64   # the whole step-0 batch: the very work of one GPU step
+            n_cpu_frames = 64   # a quarter of step 0 (10-20 s of CPU work)
             seeds = step_seeds(0)[:n_cpu_frames]
             t1 = time.perf_counter()
             _, ost = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=threads)

@@ -924,16 +924,32 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
 
     const uint32_t tiles_x = (d->width + 7) / 8, tiles_y = (d->height + 7) / 8;
     const uint32_t tiles = tiles_x * tiles_y;
-    // frames per launch: bounded by a 2 GiB frame buffer and by 32-bit path ids
+    // Frames per launch.  The persistent kernel ends with a tail in which most waves have run out of
+    // work while a few finish their longest paths (about 1 ms at 1080p, whatever the launch size), so
+    // launches should be long: one launch covers as many frames as the frame buffer may hold --
+    // 16 GiB by default, at most a quarter of the free device memory, MI355PT_FRAME_BUF_GB overrides --
+    // and 32-bit path ids allow.  Measured on MI355X, scene1 1080p, 256 frames: 4 launches 32.4 ms,
+    // 2 launches 30.3 ms, 1 launch 29.0 ms.
     uint32_t batch = cfg.max_batch;
+    if (const char* e = getenv("MI355PT_MAX_BATCH")) batch = (uint32_t)std::max(0, atoi(e));  // development switch
     if (batch == 0) {
-        size_t by_mem = ((size_t)2 << 30) / ((size_t)d->n_pix * sizeof(f4));
-        batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_mem, 64));
+        size_t budget = (size_t)16 << 30;
+        if (const char* e = getenv("MI355PT_FRAME_BUF_GB")) {
+            budget = (size_t)std::max(1, atoi(e)) << 30;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t held = (d->frame_cap[0] + d->frame_cap[1]) * sizeof(f4);  // ours already
+                budget = std::min(budget, (free_b + held) / 4);
+            }
+        }
+        size_t by_mem = budget / ((size_t)d->n_pix * sizeof(f4));
+        batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_mem, 4096));
     }
     batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
     size_t need = (size_t)batch * d->n_pix;
-    for (uint32_t b = 0; b < 2; b++) {
+    for (uint32_t b = 0; b < (d->overlap ? 2u : 1u); b++) {
         if (need <= d->frame_cap[b]) continue;
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
         (void)hipFree(d->frame_buf[b]);
@@ -1051,7 +1067,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
 
     for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
         const uint32_t nb = std::min(batch, n_frames - f0);
-        const uint32_t b = d->next_buf;
+        const uint32_t b = d->overlap ? d->next_buf : 0u;
         d->next_buf ^= 1u;
         P.frame_out = d->frame_buf[b];
         P.total_units = nb * tiles;

@@ -188,13 +188,19 @@ def test_renderer_state_machine(pa, orc):
         assert bits_equal(ref4, r.read_accum())
 
 
-def test_frame_order_and_batching_do_not_change_bits(pa):
+def test_frame_order_and_batching_do_not_change_bits(pa, monkeypatch):
     sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
     W, H = 128, 72
-    seeds = list(range(100, 170))  # 70 frames: more than one launch batch
+    seeds = list(range(100, 170))  # 70 frames
     with pa.Renderer(sc, pa.Settings(), W, H) as r:
         r.render(seeds=seeds)
         one = r.read_accum()
+        assert r.stats()["launches"] == 1
+        r.clear()
+        monkeypatch.setenv("MI355PT_MAX_BATCH", "16")   # the same call split into 5 launches
+        r.render(seeds=seeds)
+        assert bits_equal(one, r.read_accum()) and r.stats()["launches"] == 5
+        monkeypatch.delenv("MI355PT_MAX_BATCH")
         r.clear()
         r.render(seeds=seeds[:33])
         r.render(seeds=seeds[33:34])
@@ -207,9 +213,10 @@ def test_frame_order_and_batching_do_not_change_bits(pa):
     assert np.all(one[..., 3] == 1.0) and np.isfinite(one).all()
 
 
-def test_queued_renders_equal_blocking_renders(pa):
-    # render_async pipelines accumulation (second stream, two frame buffers) under the next path kernel;
-    # frames must still be added in order
+def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
+    # render_async queues launches without joining; frames must still be added in order, also when a
+    # call is split into several launches (forced here: 64 frames per launch)
+    monkeypatch.setenv("MI355PT_MAX_BATCH", "64")
     sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
     W, H = 256, 144
     seeds = np.arange(1, 215, dtype=np.uint32) * np.uint32(2654435761)
