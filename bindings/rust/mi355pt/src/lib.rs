@@ -110,8 +110,8 @@ impl Renderer {
     pub fn render_with_seeds(&mut self, seeds: &[u32]) -> Result<()> {
         self.check(unsafe { sys::mi355pt_render(self.ctx, seeds.len() as u32, seeds.as_ptr()) })
     }
-    /// Queue frames without waiting (overlaps accumulation with the next call's path kernel); `wait`
-    /// or any reading call joins.
+    /// Queue frames without waiting (consecutive calls run back to back on the device); `wait` or any
+    /// reading call joins.
     pub fn render_async(&mut self, frames: u32) -> Result<()> {
         self.check(unsafe { sys::mi355pt_render_async(self.ctx, frames, std::ptr::null()) })
     }

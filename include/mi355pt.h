@@ -116,9 +116,8 @@ int mi355pt_clear(mi355pt_ctx* ctx);
  * seed of the k-th frame since the last clear is mi355pt_frame_seed(base_seed, k).  Frames are added
  * to each texel in order.  Synchronous: the accumulator is complete on return. */
 int mi355pt_render(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
-/* The same without waiting: returns once the frames are queued on the device, so the next call's path
- * kernel overlaps this call's frame-order accumulation (two streams, two frame buffers).  The seeds are
- * copied before returning.  mi355pt_wait() -- and every call that reads or replaces device state
+/* The same without waiting: returns once the frames are queued on the device, so consecutive calls run
+ * back to back without the host in between.  The seeds are copied before returning.  mi355pt_wait() -- and every call that reads or replaces device state
  * (read_accum, to_rgb8, save_png, stats_get, accum_device_ptr, clear, resize, set_scene, set_bvh,
  * destroy) -- first waits for everything queued; a device error of queued work is reported there.
  * No counterpart in the reference, which blocks on device.poll(Wait) after every frame

@@ -40,9 +40,7 @@ bool clear(Device* d, std::string& err);
 // Accumulates n_frames frames (seeds[f] = Globals.seed of frame f) in frame order.
 bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
             RenderStats& stats, std::string& err);
-// The same in two halves: enqueue() returns once the work is queued on the device (path kernels on the
-// render stream, frame-order accumulation on a second stream, overlapping the next batch's path kernel);
-// finish() waits for everything queued so far and folds its timings and counters into `stats`.
+// The same in two halves: enqueue() returns once the work is queued on the device's stream; finish() waits for everything queued so far and folds its timings and counters into `stats`.
 // Every other entry point below expects finish() to have been called.
 bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
              RenderStats& stats, std::string& err);

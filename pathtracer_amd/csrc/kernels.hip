@@ -587,16 +587,12 @@ struct Device {
     uint32_t width = 0, height = 0, n_pix = 0;
     f4* accum = nullptr;
     uint32_t* pixel_hash = nullptr;
-    // Two frame buffers and a second stream allow the accumulation kernel of one batch to run under the
-    // path kernel of the next.  Off by default (MI355PT_OVERLAP=1 turns it on): measured on MI355X the
-    // 8 100 small accumulation workgroups delay the placement of the persistent kernel's large ones and
-    // a 64-frame 1080p step takes 9.35 ms instead of 8.45 + 0.38 ms back to back.
-    f4* frame_buf[2] = {nullptr, nullptr};
-    size_t frame_cap[2] = {0, 0};  // in f4 elements
-    hipStream_t resolve_stream = nullptr;
-    bool overlap = false;
-    hipEvent_t resolve_done[2] = {nullptr, nullptr};  // last accumulation that read frame_buf[i]
-    uint32_t next_buf = 0;
+    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
+    // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
+    // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
+    // way of the persistent kernel's workgroup placement.)
+    f4* frame_buf = nullptr;
+    size_t frame_cap = 0;  // in f4 elements
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
     size_t seeds_cap = 0, seeds_head = 0;
     std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
@@ -660,18 +656,6 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
         return false;
     }
     (void)hipMemset(d->counters, 0, 256);
-    // The accumulation kernel only needs HBM bandwidth and runs under the next batch's path kernel; it
-    // gets the lowest priority so that the persistent path kernel's workgroups are placed first.
-    int least_prio = 0, greatest_prio = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least_prio, &greatest_prio);
-    if (hipStreamCreateWithPriority(&d->resolve_stream, hipStreamNonBlocking, least_prio) != hipSuccess ||
-        hipEventCreateWithFlags(&d->resolve_done[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&d->resolve_done[1], hipEventDisableTiming) != hipSuccess) {
-        destroy(d);
-        err = "hipStreamCreate / hipEventCreate failed";
-        return false;
-    }
-    if (const char* oenv = getenv("MI355PT_OVERLAP")) d->overlap = atoi(oenv) != 0;
     *out = d;
     return true;
 }
@@ -680,17 +664,12 @@ void destroy(Device* d) {
     if (!d) return;
     (void)hipSetDevice(d->id);
     if (d->stream) (void)hipStreamSynchronize(d->stream);
-    if (d->resolve_stream) (void)hipStreamSynchronize(d->resolve_stream);
     for (auto& t : d->timed) d->event_pool.push_back(t.begin), d->event_pool.push_back(t.end);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
-    for (hipEvent_t e : d->resolve_done)
-        if (e) (void)hipEventDestroy(e);
-    if (d->resolve_stream) (void)hipStreamDestroy(d->resolve_stream);
     (void)hipFree(d->scene);
     (void)hipFree(d->accum);
     (void)hipFree(d->pixel_hash);
-    (void)hipFree(d->frame_buf[0]);
-    (void)hipFree(d->frame_buf[1]);
+    (void)hipFree(d->frame_buf);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
@@ -718,14 +697,9 @@ bool device_info(Device* d, int* cus, int* clock_khz, size_t* lds_per_cu, char n
 bool synchronize(Device* d, std::string& err) {
     PT_HIP(hipSetDevice(d->id));
     PT_HIP(hipStreamSynchronize(d->stream));
-    PT_HIP(hipStreamSynchronize(d->resolve_stream));
     return true;
 }
-#define PT_SYNC_ALL(d)                                        \
-    do {                                                      \
-        PT_HIP(hipStreamSynchronize((d)->stream));            \
-        PT_HIP(hipStreamSynchronize((d)->resolve_stream));    \
-    } while (0)
+#define PT_SYNC_ALL(d) PT_HIP(hipStreamSynchronize((d)->stream))
 
 static uint32_t stack_bytes(const SceneLayout& L, uint32_t block) { return std::max(1u, L.max_depth) * block * 4u; }
 
@@ -939,7 +913,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         } else {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                const size_t held = (d->frame_cap[0] + d->frame_cap[1]) * sizeof(f4);  // ours already
+                const size_t held = d->frame_cap * sizeof(f4);  // ours already
                 budget = std::min(budget, (free_b + held) / 4);
             }
         }
@@ -949,14 +923,13 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
     size_t need = (size_t)batch * d->n_pix;
-    for (uint32_t b = 0; b < (d->overlap ? 2u : 1u); b++) {
-        if (need <= d->frame_cap[b]) continue;
+    if (need > d->frame_cap) {
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
-        (void)hipFree(d->frame_buf[b]);
-        d->frame_buf[b] = nullptr;
-        d->frame_cap[b] = 0;
-        PT_HIP(hipMalloc(&d->frame_buf[b], need * sizeof(f4)));
-        d->frame_cap[b] = need;
+        (void)hipFree(d->frame_buf);
+        d->frame_buf = nullptr;
+        d->frame_cap = 0;
+        PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
+        d->frame_cap = need;
     }
     if (n_frames > d->seeds_cap) {
         if (!finish(d, stats, err)) return false;
@@ -1067,15 +1040,10 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
 
     for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
         const uint32_t nb = std::min(batch, n_frames - f0);
-        const uint32_t b = d->overlap ? d->next_buf : 0u;
-        d->next_buf ^= 1u;
-        P.frame_out = d->frame_buf[b];
+        P.frame_out = d->frame_buf;
         P.total_units = nb * tiles;
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = dev_seeds + f0;
-        hipStream_t rs = d->overlap ? d->resolve_stream : d->stream;
-        // the accumulation that last read this frame buffer must be done before it is overwritten
-        if (d->overlap && d->in_flight) PT_HIP(hipStreamWaitEvent(d->stream, d->resolve_done[b], 0));
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
         Device::Timed tr{take_event(d), take_event(d), false};
         PT_HIP(hipEventRecord(tr.begin, d->stream));
@@ -1086,16 +1054,14 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         d->timed.push_back(tr);
         if (!ok) return false;
         PT_HIP(hipEventRecord(tr.end, d->stream));
-        // accumulate in frame order; batches stay ordered among themselves on whichever stream runs this
+        // accumulate in frame order (same stream: launches of one context never overlap)
         Device::Timed ts{take_event(d), take_event(d), true};
-        if (d->overlap) PT_HIP(hipStreamWaitEvent(rs, tr.end, 0));
-        PT_HIP(hipEventRecord(ts.begin, rs));
-        hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, rs, d->accum,
-                           d->frame_buf[b], d->n_pix, nb, d->counters + 8);
+        PT_HIP(hipEventRecord(ts.begin, d->stream));
+        hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum,
+                           d->frame_buf, d->n_pix, nb, d->counters + 8);
         d->timed.push_back(ts);
         PT_HIP(hipGetLastError());
-        PT_HIP(hipEventRecord(ts.end, rs));
-        if (d->overlap) PT_HIP(hipEventRecord(d->resolve_done[b], rs));
+        PT_HIP(hipEventRecord(ts.end, d->stream));
         d->in_flight = true;
         d->pending_launches++;
     }
