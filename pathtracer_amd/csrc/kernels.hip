@@ -23,7 +23,19 @@
 namespace pt {
 namespace gpu {
 
-constexpr uint32_t CHUNK_UNITS = 4;    // 64-path units taken from the queue per atomic
+// Work queue: waves take chunks of 64-path units from one counter.  One returning atomic per chunk on a
+// single address is a device-wide serial resource: with fixed 4-unit chunks it cost 10 % of a scene1
+// launch on MI355X (65 M atomics/s) and two thirds of a scene2 launch.  Chunks are therefore up to
+// RenderParams::chunk_max units while plenty of work is left and shrink towards the end of the queue,
+// where balance matters: chunk = what is left / (2 * waves), clamped to [1, chunk_max].  The host sets
+// chunk_max to 32 for scenes in LDS and to 4 for scenes in global memory: there the waves should stay
+// close together in the image, so that the part of the tree they walk stays in the caches (10 M spheres
+// at 3840x2160: 13.0 ms per 8 frames with 4-unit chunks, 28 ms with 32-unit chunks).
+__device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t taken_to, float inv_two_waves,
+                                                       uint32_t chunk_max) {
+    const uint32_t left = total - min(total, taken_to);
+    return max(1u, min(chunk_max, (uint32_t)((float)left * inv_two_waves)));
+}
 
 #define PT_LDS(T) __attribute__((address_space(3))) T
 
@@ -110,9 +122,15 @@ struct RenderParams {
     uint32_t width, height, tiles_x, tiles_per_frame, n_pix;
     int32_t samples, depth;
     uint32_t total_units;  // frames in this launch * tiles_per_frame
+    // Work order: unit u = (tile rank u / n_frames, frame u % n_frames); tile = tile_perm[rank] (or the
+    // rank itself without a permutation).  The permutation lists tiles by decreasing measured cost, so
+    // the long paths start early and the queue ends with the cheapest tiles.
+    uint32_t n_frames;
+    float inv_n_frames;
+    const uint32_t* tile_perm;
     const uint32_t* seeds;       // one per frame of this launch
     const uint32_t* pixel_hash;  // [n_pix]
-    f4* frame_out;               // [frames][n_pix]: rgb = final_colour / samples, w = rays traced
+    f4* frame_out;               // [frame][tile rank][slot]: rgb = final_colour / samples, w = rays traced
     uint32_t* work_counter;
     unsigned long long* counters;  // nodes, tests, accepted, bounce[5]
     uint32_t scene_lds_bytes;
@@ -122,6 +140,8 @@ struct RenderParams {
                       // terminal, opaque, glass, idle
     float inv_tiles_x, inv_tiles_per_frame;
     uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
+    float inv_two_waves;  // 1 / (2 * waves in the grid), for the chunk size
+    uint32_t chunk_max;
     // SCENE_GLOBAL only: scene_lds_bytes is the node prefix kept in LDS, the stack keeps
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
     int32_t* stack_spill;
@@ -189,6 +209,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
 
     // wave state (uniform)
     uint32_t next = 0, end = 0;
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_two_waves, P.chunk_max);
     bool exhausted = false;
 
     for (;;) {
@@ -198,28 +219,31 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
             if (next == end) {
                 if (exhausted) break;
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(P.work_counter, CHUNK_UNITS);
+                if (lane == 0) base = atomicAdd(P.work_counter, chunk);
                 base = __shfl(base, 0);
                 if (base >= P.total_units) {
                     exhausted = true;
                     break;
                 }
                 next = base * 64u;
-                end = min(base + CHUNK_UNITS, P.total_units) * 64u;
+                end = min(base + chunk, P.total_units) * 64u;
+                chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_two_waves, P.chunk_max);
             }
             const uint32_t avail = end - next;
             const uint32_t rank = lane_rank(m);
             if (!alive && rank < avail) {
                 const uint32_t pid = next + rank;
                 const uint32_t unit = pid >> 6, slot = pid & 63u;
-                const uint32_t frame = unit / P.tiles_per_frame;
-                const uint32_t tile = unit - frame * P.tiles_per_frame;
+                const uint32_t tile_rank = unit / P.n_frames;
+                const uint32_t frame = unit - tile_rank * P.n_frames;
+                const uint32_t tile = P.tile_perm ? P.tile_perm[tile_rank] : tile_rank;
+                const uint32_t result_index = (frame * P.tiles_per_frame + tile_rank) * 64u + slot;
                 uint32_t px, py;
                 tile_pixel(tile, slot, P.tiles_x, px, py);
                 if (px < P.width && py < P.height) {
                     const uint32_t pix = py * P.width + px;
                     ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
-                    out_index = frame * P.n_pix + pix;
+                    out_index = result_index;
                     pxy = px | (py << 16);
                     final_colour = mk(0.0f, 0.0f, 0.0f);
                     sample_i = 0;
@@ -343,13 +367,14 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     w.cur = LANE_IDLE;
     uint32_t mbits = 0;  // material word of the hit, valid in the scatter states
     V3 final_colour = mk(0.0f, 0.0f, 0.0f);
-    uint32_t out_index = 0, pxy = 0, rays = 0;
+    uint32_t out_index = 0, pxy = 0, rays = 0;  // rays of the lane's current path
     int32_t sample_i = 0;
     Counters cnt = {0, 0, 0};
     uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
     uint32_t ph_exec[PH_COUNT] = {0}, ph_lanes[PH_COUNT] = {0};  // COUNT: wave-level step executions
 
     uint32_t next = 0, end = 0;  // wave-uniform: the wave's chunk of the path queue
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_two_waves, P.chunk_max);
     bool exhausted = false;
     bool force = false;
 
@@ -367,7 +392,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 o4.y = final_colour.y / fs;
                 o4.z = final_colour.z / fs;
             }
-            o4.w = 0.0f;
+            o4.w = (float)rays;  // summed per pixel by the accumulation kernel: ray total and tile costs
             P.frame_out[out_index] = o4;
             have_path = false;
         }
@@ -466,14 +491,15 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (next == end) {
                     if (exhausted) break;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.work_counter, CHUNK_UNITS);
+                    if (lane == 0) base = atomicAdd(P.work_counter, chunk);
                     base = __shfl(base, 0);
                     if (base >= P.total_units) {
                         exhausted = true;
                         break;
                     }
                     next = base * 64u;
-                    end = min(base + CHUNK_UNITS, P.total_units) * 64u;
+                    end = min(base + chunk, P.total_units) * 64u;
+                    chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_two_waves, P.chunk_max);
                 }
                 const uint32_t avail = end - next;
                 const uint32_t rank = lane_rank(m);
@@ -482,20 +508,26 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                     const uint32_t unit = pid >> 6, slot = pid & 63u;
                     uint32_t frame, tile, tx, ty;
                     if (P.small_ids) {  // uniform: every id below 2^24, float-reciprocal division
-                        divmod24(unit, P.tiles_per_frame, P.inv_tiles_per_frame, frame, tile);
+                        divmod24(unit, P.n_frames, P.inv_n_frames, tile, frame);
+                    } else {
+                        tile = unit / P.n_frames, frame = unit - tile * P.n_frames;
+                    }
+                    const uint32_t result_index = (frame * P.tiles_per_frame + tile) * 64u + slot;
+                    if (P.tile_perm) tile = P.tile_perm[tile];
+                    if (P.small_ids) {
                         divmod24(tile, P.tiles_x, P.inv_tiles_x, ty, tx);
                     } else {
-                        frame = unit / P.tiles_per_frame, tile = unit - frame * P.tiles_per_frame;
                         ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
                     }
                     const uint32_t px = tx * 8u + (slot & 7u), py = ty * 8u + (slot >> 3);
                     if (px < P.width && py < P.height) {
                         const uint32_t pix = py * P.width + px;
                         ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
-                        out_index = frame * P.n_pix + pix;
+                        out_index = result_index;
                         pxy = px | (py << 16);
                         final_colour = mk(0.0f, 0.0f, 0.0f);
                         sample_i = 0;
+                        rays = 0;
                         have_path = true;
                     }
                 }
@@ -523,10 +555,6 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         }
     }
 
-    {
-        unsigned long long r = wave_sum((unsigned long long)rays);
-        if (lane == 0 && r) atomicAdd(&P.counters[9], r);
-    }
     if (COUNT) {
         unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
                                    bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
@@ -545,25 +573,78 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     }
 }
 
-// accum[p] += vec4(frame[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side.
-__global__ void pt_resolve_kernel(f4* accum, const f4* frames, uint32_t n_pix, uint32_t n_frames,
-                                  unsigned long long* ray_total) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+constexpr uint32_t RAY_SLOTS = 64, RAY_SLOT_STRIDE = 16;  // 64 counters, 128 bytes apart
+
+// accum[p] += vec4(result[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side
+// (total, and per tile into `tile_cost` when given: the input of pt_tile_order_kernel).  Results lie in
+// [frame][tile rank][slot] order, ranks being those of the launch that produced them: one thread per
+// (tile rank, slot), i.e. one wave per tile; at any moment all waves stream through the same frame.
+// (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
+// measured 6x slower at 3840x2160.)
+__global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                  uint32_t tiles, uint32_t n_frames, const uint32_t* tile_perm,
+                                  unsigned long long* ray_total, float* tile_cost) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rank = gid >> 6, slot = gid & 63u;
     unsigned long long rays = 0;
-    if (i < n_pix) {
-        f4 a = accum[i];
-        for (uint32_t f = 0; f < n_frames; f++) {
-            f4 s = frames[(size_t)f * n_pix + i];
-            a.x += s.x;
-            a.y += s.y;
-            a.z += s.z;
-            a.w += 0.0f;
-            rays += (unsigned long long)s.w;
+    uint32_t tile = 0;
+    if (rank < tiles) {
+        tile = tile_perm ? tile_perm[rank] : rank;
+        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
+        if (px < width && py < height) {
+            const uint32_t i = py * width + px;
+            f4 a = accum[i];
+            const f4* src = results + (size_t)rank * 64u + slot;
+            const size_t frame_stride = (size_t)tiles * 64u;
+            for (uint32_t f = 0; f < n_frames; f++) {
+                f4 s = src[(size_t)f * frame_stride];
+                a.x += s.x;
+                a.y += s.y;
+                a.z += s.z;
+                a.w += 0.0f;
+                rays += (unsigned long long)s.w;
+            }
+            accum[i] = a;
         }
-        accum[i] = a;
     }
     rays = wave_sum(rays);
-    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(ray_total, rays);
+    if ((threadIdx.x & 63u) == 0) {
+        // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
+        // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
+        if (rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+        if (tile_cost && rank < tiles) tile_cost[tile] = (float)rays;
+    }
+}
+
+// Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
+// workgroup, a 256-bucket counting sort.  Ties land in arbitrary order, which nothing depends on.
+constexpr int ORDER_BLK = 1024;
+__global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm) {
+    __shared__ uint32_t hist[256];
+    __shared__ float red[ORDER_BLK];
+    float mx = 0.0f;
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) mx = fmaxf(mx, tile_cost[t]);
+    red[threadIdx.x] = mx;
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    for (int o = ORDER_BLK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    const float scale = 255.0f / fmaxf(red[0], 1.0f);
+    auto bucket = [&](float c) { return 255u - min(255u, (uint32_t)(c * scale)); };  // 0 = most expensive
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) atomicAdd(&hist[bucket(tile_cost[t])], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive prefix over 256 buckets
+        uint32_t run = 0;
+        for (int b = 0; b < 256; b++) {
+            const uint32_t n = hist[b];
+            hist[b] = run;
+            run += n;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) perm[atomicAdd(&hist[bucket(tile_cost[t])], 1u)] = t;
 }
 
 __global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
@@ -593,6 +674,12 @@ struct Device {
     // way of the persistent kernel's workgroup placement.)
     f4* frame_buf = nullptr;
     size_t frame_cap = 0;  // in f4 elements
+    // Cost-ordered work: rays per tile of the last launch, tiles sorted by it, and what it was measured for
+    float* tile_cost = nullptr;    // [tiles]
+    uint32_t* tile_perm = nullptr; // [tiles]
+    bool perm_valid = false;
+    Camera64 perm_cam{};
+    int32_t perm_depth = 0, perm_samples = 0;
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
     size_t seeds_cap = 0, seeds_head = 0;
     std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
@@ -608,7 +695,8 @@ struct Device {
     int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
     size_t spill_cap = 0;            // in entries
     uint32_t* work_counter = nullptr;  // [1]
-    unsigned long long* counters = nullptr;  // [8] kernel counters + [1] rays
+    unsigned long long* counters = nullptr;  // [8] kernel counters, watchdog, step statistics
+    unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] ray totals of the accumulation kernel
 };
 
 #define PT_HIP(call)                                                                          \
@@ -650,12 +738,14 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
         }
         d->own_stream = true;
     }
-    if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, 256) != hipSuccess) {
+    if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, 256) != hipSuccess ||
+        hipMalloc(&d->ray_slots, RAY_SLOTS * RAY_SLOT_STRIDE * 8) != hipSuccess) {
         destroy(d);
         err = "hipMalloc failed";
         return false;
     }
     (void)hipMemset(d->counters, 0, 256);
+    (void)hipMemset(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8);
     *out = d;
     return true;
 }
@@ -670,10 +760,13 @@ void destroy(Device* d) {
     (void)hipFree(d->accum);
     (void)hipFree(d->pixel_hash);
     (void)hipFree(d->frame_buf);
+    (void)hipFree(d->tile_cost);
+    (void)hipFree(d->tile_perm);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
     (void)hipFree(d->counters);
+    (void)hipFree(d->ray_slots);
     if (d->own_stream && d->stream) (void)hipStreamDestroy(d->stream);
     delete d;
 }
@@ -718,6 +811,7 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
     PT_HIP(hipMemcpy(d->scene, blob, layout.total_bytes, hipMemcpyHostToDevice));
     d->layout = layout;
     d->have_scene = true;
+    d->perm_valid = false;
     d->scene_in_lds = bytes + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
@@ -742,10 +836,17 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     uint32_t n_pix = width * height;
     (void)hipFree(d->accum);
     (void)hipFree(d->pixel_hash);
+    (void)hipFree(d->tile_cost);
+    (void)hipFree(d->tile_perm);
     d->accum = nullptr;
     d->pixel_hash = nullptr;
+    d->tile_cost = nullptr, d->tile_perm = nullptr;
+    d->perm_valid = false;
+    const size_t n_tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
     PT_HIP(hipMalloc(&d->accum, (size_t)n_pix * sizeof(f4)));
     PT_HIP(hipMalloc(&d->pixel_hash, (size_t)n_pix * sizeof(uint32_t)));
+    PT_HIP(hipMalloc(&d->tile_cost, n_tiles * sizeof(float)));
+    PT_HIP(hipMalloc(&d->tile_perm, n_tiles * sizeof(uint32_t)));
     d->width = width, d->height = height, d->n_pix = n_pix;
     hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
                        height);
@@ -764,6 +865,7 @@ bool clear(Device* d, std::string& err) {
                        v);
     PT_HIP(hipGetLastError());
     PT_HIP(hipMemsetAsync(d->counters, 0, 256, d->stream));
+    PT_HIP(hipMemsetAsync(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8, d->stream));
     PT_SYNC_ALL(d);
     return true;
 }
@@ -803,7 +905,9 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
     // never launch more waves than there are 64-path units
     uint32_t max_blocks = (P.total_units + (BLK / 64) - 1u) / (BLK / 64);
     grid = std::max(1u, std::min(grid, max_blocks));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, P);
+    RenderParams Q = P;
+    Q.inv_two_waves = 1.0f / (2.0f * (float)grid * (float)(BLK / 64));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, Q);
     PT_HIP(hipGetLastError());
     return true;
 }
@@ -859,7 +963,12 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     stats.tests = host_counters[1];
     stats.accepted = host_counters[2];
     for (int k = 0; k < 5; k++) stats.bounces[k] = host_counters[3 + k];
-    stats.rays = host_counters[8] + host_counters[9];
+    {
+        std::vector<unsigned long long> slots(RAY_SLOTS * RAY_SLOT_STRIDE);
+        PT_HIP(hipMemcpy(slots.data(), d->ray_slots, slots.size() * 8, hipMemcpyDeviceToHost));
+        stats.rays = 0;
+        for (uint32_t k = 0; k < RAY_SLOTS; k++) stats.rays += slots[(size_t)k * RAY_SLOT_STRIDE];
+    }
     stats.paths += d->pending_paths;
     stats.launches += d->pending_launches;
     d->pending_paths = 0;
@@ -917,12 +1026,12 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
                 budget = std::min(budget, (free_b + held) / 4);
             }
         }
-        size_t by_mem = budget / ((size_t)d->n_pix * sizeof(f4));
+        size_t by_mem = budget / ((size_t)tiles * 64u * sizeof(f4));
         batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_mem, 4096));
     }
     batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
-    size_t need = (size_t)batch * d->n_pix;
+    size_t need = (size_t)batch * tiles * 64u;  // whole tiles: [tile rank][frame][64 slots]
     if (need > d->frame_cap) {
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
         (void)hipFree(d->frame_buf);
@@ -977,6 +1086,11 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // MI355PT_LEAF=loop: a leaf step tests all spheres of the lane's leaf (development switch)
         const char* lenv = getenv("MI355PT_LEAF");
         P.leaf_one = (lenv && strcmp(lenv, "loop") == 0) ? 0u : 1u;
+    }
+    {
+        const char* cenv = getenv("MI355PT_CHUNK");  // development switch
+        P.chunk_max = d->scene_in_lds ? 32u : 4u;
+        if (cenv && atoi(cenv) > 0) P.chunk_max = (uint32_t)std::min(1024, atoi(cenv));
     }
     const bool in_lds = d->scene_in_lds;
     const int scene_mode = in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
@@ -1038,10 +1152,18 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         return false;
     }
 
+    // MI355PT_TILE_ORDER=0 keeps row-major tile order (development switch)
+    const char* tenv = getenv("MI355PT_TILE_ORDER");
+    const bool order_tiles = !(tenv && atoi(tenv) == 0);
+    bool use_perm = order_tiles && d->perm_valid && memcmp(&cam, &d->perm_cam, sizeof cam) == 0 &&
+                    cfg.depth == d->perm_depth && cfg.samples == d->perm_samples;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
         const uint32_t nb = std::min(batch, n_frames - f0);
         P.frame_out = d->frame_buf;
         P.total_units = nb * tiles;
+        P.n_frames = nb;
+        P.inv_n_frames = 1.0f / (float)nb;
+        P.tile_perm = use_perm ? d->tile_perm : nullptr;
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = dev_seeds + f0;
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
@@ -1057,10 +1179,22 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // accumulate in frame order (same stream: launches of one context never overlap)
         Device::Timed ts{take_event(d), take_event(d), true};
         PT_HIP(hipEventRecord(ts.begin, d->stream));
-        hipLaunchKernelGGL(pt_resolve_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum,
-                           d->frame_buf, d->n_pix, nb, d->counters + 8);
+        // Re-measure the tile costs on launches that are long enough to be representative.
+        const bool measure = order_tiles && nb >= 8u;
+        hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
+                           d->frame_buf, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
+                           measure ? d->tile_cost : nullptr);
         d->timed.push_back(ts);
         PT_HIP(hipGetLastError());
+        if (measure) {
+            hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(ORDER_BLK), 0, d->stream, d->tile_cost, tiles,
+                               d->tile_perm);
+            PT_HIP(hipGetLastError());
+            d->perm_valid = true;
+            d->perm_cam = cam;
+            d->perm_depth = cfg.depth, d->perm_samples = cfg.samples;
+            use_perm = true;   // later launches of this call are ordered after the kernel above
+        }
         PT_HIP(hipEventRecord(ts.end, d->stream));
         d->in_flight = true;
         d->pending_launches++;

@@ -32,7 +32,7 @@ for name in sys.argv[1:] or ["c1", "c2", "c3a", "c3b"]:
     t0 = time.time()
     r = pa.Renderer(sc, pa.Settings(1, 50), W, H)
     t_build = time.time() - t0
-    r.render(min(F, 4))            # warm-up
+    r.render(min(F, 16))           # warm-up (long enough to measure the tile costs once)
     r.clear()
     t0 = time.time()
     r.render(F)
