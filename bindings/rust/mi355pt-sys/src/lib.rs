@@ -11,6 +11,7 @@ pub const MI355PT_ERR_NOMEM: c_int = -5;
 
 pub const MI355PT_BVH_SAH: u32 = 0;
 pub const MI355PT_BVH_REFERENCE: u32 = 1;
+pub const MI355PT_BVH_LBVH: u32 = 2;
 pub const MI355PT_FLAG_GLASS_SHORT_CIRCUIT: u32 = 1 << 0;
 pub const MI355PT_FLAG_COUNT: u32 = 1 << 1;
 

@@ -8,6 +8,7 @@ _LIB_PATH = os.environ.get("MI355PT_LIB") or os.path.join(_HERE, "libmi355pt.so"
 
 BVH_SAH = 0
 BVH_REFERENCE = 1
+BVH_LBVH = 2
 FLAG_GLASS_SHORT_CIRCUIT = 1 << 0
 FLAG_COUNT = 1 << 1
 

@@ -80,6 +80,13 @@ int install_tree(mi355pt_ctx* c, const Node48* ref_nodes, size_t n_ref_nodes) {
     std::string err;
     std::vector<char> blob;
     c->have_scene = false;
+    if (c->desc.bvh_mode == MI355PT_BVH_LBVH && !ref_nodes) {
+        c->bvh = Bvh2{};
+        if (!gpu::build_scene_lbvh(c->dev, a, c->layout, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        c->have_scene = true;
+        c->dirty = true;
+        return MI355PT_OK;
+    }
     if (!pack_scene(a, c->desc.bvh_mode == MI355PT_BVH_REFERENCE, ref_nodes, n_ref_nodes, blob, c->layout, c->bvh, err))
         return fail(c, MI355PT_ERR_ARG, err);
     if (!gpu::upload_scene(c->dev, blob.data(), c->layout, err)) return fail(c, MI355PT_ERR_DEVICE, err);
@@ -112,7 +119,7 @@ int mi355pt_create(const mi355pt_desc* desc, mi355pt_ctx** out) {
     if (!desc || !out) return fail(nullptr, MI355PT_ERR_ARG, "create: null argument");
     *out = nullptr;
     if (desc->width == 0 || desc->height == 0) return fail(nullptr, MI355PT_ERR_ARG, "create: zero image size");
-    if (desc->bvh_mode > MI355PT_BVH_REFERENCE) return fail(nullptr, MI355PT_ERR_ARG, "create: unknown bvh_mode");
+    if (desc->bvh_mode > MI355PT_BVH_LBVH) return fail(nullptr, MI355PT_ERR_ARG, "create: unknown bvh_mode");
     mi355pt_ctx* c = new (std::nothrow) mi355pt_ctx();
     if (!c) return fail(nullptr, MI355PT_ERR_NOMEM, "create: out of memory");
     c->desc = *desc;
@@ -324,8 +331,8 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
     for (int k = 0; k < 12; k++) out->phase[k] = c->stats.phase[k];
     out->render_ms = c->stats.render_ms, out->resolve_ms = c->stats.resolve_ms;
     out->launches = c->stats.launches;
-    out->bvh_nodes = (uint32_t)c->bvh.nodes.size();
-    out->bvh_depth = c->bvh.max_depth;
+    out->bvh_nodes = c->have_scene ? c->layout.n_nodes : 0u;
+    out->bvh_depth = c->have_scene ? c->layout.max_depth : 0u;
     out->scene_bytes = c->layout.total_bytes;
     out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
     out->node_format = c->have_scene ? c->layout.node_half : 0u;

@@ -6,6 +6,7 @@
 #include "pt_types.h"
 
 namespace pt {
+struct SceneArrays;  // scene_pack.h
 namespace gpu {
 
 struct Device;  // one GPU: stream, scene blob, accumulator, sample buffer, work counter
@@ -35,6 +36,10 @@ struct RenderConfig {
 bool create(int device_id, void* stream, Device** out, std::string& err);
 void destroy(Device* d);
 bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err);
+// Builds the tree on the device (lbvh.hip) from the scene arrays and leaves the finished blob there.
+bool build_scene_lbvh(Device* d, const pt::SceneArrays& arrays, SceneLayout& layout, std::string& err);
+// Records `layout` as the scene now in d's blob and decides where the kernels read it from.
+bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err);
 bool resize(Device* d, uint32_t width, uint32_t height, std::string& err);
 bool clear(Device* d, std::string& err);
 // Accumulates n_frames frames (seeds[f] = Globals.seed of frame f) in frame order.

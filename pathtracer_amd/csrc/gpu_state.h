@@ -1,0 +1,75 @@
+// State of one GPU context and the error-check macro, shared by the .hip files of the library.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "gpu.h"
+#include "pt_types.h"
+
+namespace pt {
+namespace gpu {
+
+constexpr uint32_t RAY_SLOTS = 64, RAY_SLOT_STRIDE = 16;  // 64 ray counters, 128 bytes apart
+
+struct Device {
+    int id = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipDeviceProp_t prop;
+
+    char* scene = nullptr;
+    size_t scene_cap = 0;
+    SceneLayout layout{};
+    bool have_scene = false;
+    bool scene_in_lds = false;
+
+    uint32_t width = 0, height = 0, n_pix = 0;
+    f4* accum = nullptr;
+    uint32_t* pixel_hash = nullptr;
+    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
+    // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
+    // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
+    // way of the persistent kernel's workgroup placement.)
+    f4* frame_buf = nullptr;
+    size_t frame_cap = 0;  // in f4 elements
+    // Cost-ordered work: rays per tile of the last launch, tiles sorted by it, and what it was measured for
+    float* tile_cost = nullptr;    // [tiles]
+    uint32_t* tile_perm = nullptr; // [tiles]
+    bool perm_valid = false;
+    Camera64 perm_cam{};
+    int32_t perm_depth = 0, perm_samples = 0;
+    uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
+    size_t seeds_cap = 0, seeds_head = 0;
+    std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
+    struct Timed {
+        hipEvent_t begin, end;
+        bool resolve;
+    };
+    std::vector<Timed> timed;          // launches enqueued since the last finish()
+    std::vector<hipEvent_t> event_pool;
+    bool in_flight = false;
+    uint64_t pending_paths = 0;
+    uint32_t pending_launches = 0;
+    int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
+    size_t spill_cap = 0;            // in entries
+    uint32_t* work_counter = nullptr;  // [1]
+    unsigned long long* counters = nullptr;  // [8] kernel counters, watchdog, step statistics
+    unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] ray totals of the accumulation kernel
+};
+
+#define PT_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+            return false;                                                                     \
+        }                                                                                     \
+    } while (0)
+
+
+}  // namespace gpu
+}  // namespace pt

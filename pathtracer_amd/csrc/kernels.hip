@@ -1,12 +1,15 @@
 // HIP kernels for gfx950 (MI355X) and their launch code.
 //
-//   pt_hash_kernel     per-pixel seed hash (compute.wgsl:392-400), once per resize
-//   pt_render_kernel   persistent path kernel: every lane owns one (pixel, frame) path at a time and
-//                      pulls a new one from a work queue the moment its path ends, so divergent path
-//                      lengths (1..depth+1 rays) never idle a lane; phases per iteration:
-//                      acquire -> camera -> extend (BVH walk) -> scatter
-//   pt_resolve_kernel  adds the per-frame results to the accumulator in frame order
-//                      (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
+//   pt_hash_kernel          per-pixel seed hash (compute.wgsl:392-400), once per resize
+//   pt_render_sched_kernel  persistent path kernel (default): every lane owns one (pixel, frame) path at a
+//                           time and pulls a new one from a work queue the moment its path ends; the wave
+//                           runs one kind of step at a time (node / leaf / scatter / restart), chosen by
+//                           how many lanes wait for it
+//   pt_render_kernel        the same paths in plain lockstep (acquire -> camera -> whole BVH walk ->
+//                           scatter per iteration); kept as the simple reference for the scheduled one
+//   pt_resolve_kernel       adds the per-frame results to the accumulator in frame order
+//                           (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
+//   pt_tile_order_kernel    orders the 8x8 tiles by the rays they cost in the last launch
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -18,6 +21,7 @@
 #include <vector>
 
 #include "gpu.h"
+#include "gpu_state.h"
 #include "pt_device.h"
 
 namespace pt {
@@ -138,7 +142,7 @@ struct RenderParams {
     uint64_t watchdog_ticks;  // 100 MHz ticks after which a wave gives up (scheduling-bug guard)
     uint32_t thr[6];  // pt_render_sched_kernel: lanes that must wait for a step before it runs: node, leaf,
                       // terminal, opaque, glass, idle
-    float inv_tiles_x, inv_tiles_per_frame;
+    float inv_tiles_x;
     uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
     float inv_two_waves;  // 1 / (2 * waves in the grid), for the chunk size
     uint32_t chunk_max;
@@ -573,7 +577,6 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     }
 }
 
-constexpr uint32_t RAY_SLOTS = 64, RAY_SLOT_STRIDE = 16;  // 64 counters, 128 bytes apart
 
 // accum[p] += vec4(result[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side
 // (total, and per tile into `tile_cost` when given: the input of pt_tile_order_kernel).  Results lie in
@@ -653,61 +656,6 @@ __global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
 }
 
 // ------------------------------------------------------------------------------------------ host
-struct Device {
-    int id = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipDeviceProp_t prop;
-
-    char* scene = nullptr;
-    size_t scene_cap = 0;
-    SceneLayout layout{};
-    bool have_scene = false;
-    bool scene_in_lds = false;
-
-    uint32_t width = 0, height = 0, n_pix = 0;
-    f4* accum = nullptr;
-    uint32_t* pixel_hash = nullptr;
-    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
-    // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
-    // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
-    // way of the persistent kernel's workgroup placement.)
-    f4* frame_buf = nullptr;
-    size_t frame_cap = 0;  // in f4 elements
-    // Cost-ordered work: rays per tile of the last launch, tiles sorted by it, and what it was measured for
-    float* tile_cost = nullptr;    // [tiles]
-    uint32_t* tile_perm = nullptr; // [tiles]
-    bool perm_valid = false;
-    Camera64 perm_cam{};
-    int32_t perm_depth = 0, perm_samples = 0;
-    uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
-    size_t seeds_cap = 0, seeds_head = 0;
-    std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
-    struct Timed {
-        hipEvent_t begin, end;
-        bool resolve;
-    };
-    std::vector<Timed> timed;          // launches enqueued since the last finish()
-    std::vector<hipEvent_t> event_pool;
-    bool in_flight = false;
-    uint64_t pending_paths = 0;
-    uint32_t pending_launches = 0;
-    int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
-    size_t spill_cap = 0;            // in entries
-    uint32_t* work_counter = nullptr;  // [1]
-    unsigned long long* counters = nullptr;  // [8] kernel counters, watchdog, step statistics
-    unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] ray totals of the accumulation kernel
-};
-
-#define PT_HIP(call)                                                                          \
-    do {                                                                                      \
-        hipError_t e_ = (call);                                                               \
-        if (e_ != hipSuccess) {                                                               \
-            err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
-            return false;                                                                     \
-        }                                                                                     \
-    } while (0)
-
 bool create(int device_id, void* stream, Device** out, std::string& err) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -809,17 +757,17 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
     }
     PT_HIP(hipMemset(d->scene, 0, bytes));
     PT_HIP(hipMemcpy(d->scene, blob, layout.total_bytes, hipMemcpyHostToDevice));
+    return adopt_layout(d, layout, err);
+}
+
+bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
+    const size_t bytes = ((size_t)layout.total_bytes + 15u) & ~(size_t)15u;
     d->layout = layout;
     d->have_scene = true;
     d->perm_valid = false;
     d->scene_in_lds = bytes + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
-        d->have_scene = false;
-        return false;
-    }
-    if (d->scene_in_lds && stack_bytes(layout, 256) > 160u * 1024u) {
-        err = "scene: BVH too deep for the traversal stack";
         d->have_scene = false;
         return false;
     }
@@ -1074,7 +1022,6 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
     P.inv_tiles_x = 1.0f / (float)tiles_x;
-    P.inv_tiles_per_frame = 1.0f / (float)tiles;
     const uint32_t default_thr[6] = {16, 8, 24, 24, 8, 40};
     for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {

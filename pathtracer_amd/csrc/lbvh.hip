@@ -1,0 +1,307 @@
+// BVH construction on the GPU: Morton codes of the sphere centres, radix sort, the parallel
+// hierarchy of Karras ("Maximizing parallelism in the construction of BVHs, octrees and k-d trees",
+// HPG 2012), bottom-up box refit, then the device scene blob in the layout the path kernels walk.
+// This is the fast path for Renderer::reload_scene (mod.rs:148-155): the reference rebuilds its tree on
+// the CPU with a sort per level (bvh.rs:51-113).  The tree is of lower quality than the host's binned
+// SAH (single-sphere leaves, median-like splits): what is traced is the same, it takes more node visits.
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "gpu.h"
+#include "gpu_state.h"
+#include "scene_pack.h"
+
+namespace pt {
+namespace gpu {
+
+namespace {
+
+constexpr int BLK = 256;
+
+// order-preserving float <-> int, for atomicMin / atomicMax on floats
+__device__ __forceinline__ int ordered(float f) {
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float unordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7fffffff); }
+
+// box[0..2] = min of the centres, box[3..5] = max, as ordered ints
+__global__ void lbvh_bounds(const Sphere32* s, uint32_t n, int* box) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    int lo[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+    if (i < n)
+        for (int k = 0; k < 3; k++) lo[k] = hi[k] = ordered(s[i].pos[k]);
+    for (int k = 0; k < 3; k++) {
+        for (int o = 32; o > 0; o >>= 1) {
+            lo[k] = min(lo[k], __shfl_down(lo[k], o));
+            hi[k] = max(hi[k], __shfl_down(hi[k], o));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMin(&box[k], lo[k]);
+            atomicMax(&box[3 + k], hi[k]);
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v) {  // bit k of v -> bit 3k
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void lbvh_codes(const Sphere32* s, uint32_t n, const int* box, uint64_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int k = 0; k < 3; k++) {
+        const float lo = unordered(box[k]), hi = unordered(box[3 + k]);
+        const float ext = hi - lo;
+        const float u = ext > 0.0f ? (s[i].pos[k] - lo) / ext : 0.0f;
+        q[k] = (uint32_t)fminf(fmaxf(u * 2097152.0f, 0.0f), 2097151.0f);
+    }
+    keys[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+    vals[i] = i;
+}
+
+// length of the common prefix of the keys at sorted positions i and j (ties broken by position)
+__device__ __forceinline__ int common_prefix(const uint64_t* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const uint64_t x = keys[i] ^ keys[j];
+    return x ? __clzll((long long)x) : 64 + __clz(i ^ j);
+}
+
+// Internal node i of n-1 (node 0 is the root): its children as links (>= 0 internal, ~p leaf at sorted
+// position p) and the parent of every child.
+__global__ void lbvh_hierarchy(const uint64_t* keys, int n, int32_t* child0, int32_t* child1, int32_t* parent_of_node,
+                               int32_t* parent_of_leaf) {
+    const int i = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (i >= n - 1) return;
+    const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
+    const int dmin = common_prefix(keys, n, i, i - d);
+    int lmax = 2;
+    while (common_prefix(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (common_prefix(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = common_prefix(keys, n, i, j);
+    int s = 0, t = l;
+    do {
+        t = (t + 1) / 2;
+        if (common_prefix(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    } while (t > 1);
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    if (lo == gamma) {
+        child0[i] = ~gamma;
+        parent_of_leaf[gamma] = i;
+    } else {
+        child0[i] = gamma;
+        parent_of_node[gamma] = i;
+    }
+    if (hi == gamma + 1) {
+        child1[i] = ~(gamma + 1);
+        parent_of_leaf[gamma + 1] = i;
+    } else {
+        child1[i] = gamma + 1;
+        parent_of_node[gamma + 1] = i;
+    }
+    if (i == 0) parent_of_node[0] = -1;
+}
+
+struct Box {
+    float lo[3], hi[3];
+};
+// BoundingBox::from(&Sphere) (bounding_box.rs:17-27): min = pos - rad - 0.01, max = pos + rad + 0.01
+__device__ __forceinline__ Box sphere_box(const Sphere32& s) {
+    Box b;
+    for (int k = 0; k < 3; k++) {
+        b.lo[k] = (s.pos[k] - s.rad) - 0.01f;
+        b.hi[k] = (s.pos[k] + s.rad) + 0.01f;
+    }
+    return b;
+}
+__device__ __forceinline__ float coherent_load(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One thread per leaf walks towards the root; at every node the second thread to arrive merges the
+// boxes of both children and goes on, the first one stops.  node_box: 6 floats per internal node.
+__global__ void lbvh_refit(const Sphere32* spheres, const uint32_t* order, int n, const int32_t* child0,
+                           const int32_t* child1, const int32_t* parent_of_node, const int32_t* parent_of_leaf,
+                           int* arrived, float* node_box, int* max_depth) {
+    const int p = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (p >= n) return;
+    int depth = 0;
+    for (int up = parent_of_leaf[p]; up >= 0; up = parent_of_node[up]) depth++;
+    atomicMax(max_depth, depth);
+    int cur = parent_of_leaf[p];
+    while (cur >= 0) {
+        __threadfence();
+        if (atomicAdd(&arrived[cur], 1) == 0) return;
+        Box b;
+        for (int k = 0; k < 3; k++) b.lo[k] = INFINITY, b.hi[k] = -INFINITY;
+        const int32_t c[2] = {child0[cur], child1[cur]};
+        for (int side = 0; side < 2; side++) {
+            Box cb;
+            if (c[side] < 0) {
+                cb = sphere_box(spheres[order[~c[side]]]);
+            } else {
+                for (int k = 0; k < 3; k++) {
+                    cb.lo[k] = coherent_load(node_box + (size_t)c[side] * 6 + k);
+                    cb.hi[k] = coherent_load(node_box + (size_t)c[side] * 6 + 3 + k);
+                }
+            }
+            for (int k = 0; k < 3; k++) b.lo[k] = fminf(b.lo[k], cb.lo[k]), b.hi[k] = fmaxf(b.hi[k], cb.hi[k]);
+        }
+        for (int k = 0; k < 3; k++) node_box[(size_t)cur * 6 + k] = b.lo[k], node_box[(size_t)cur * 6 + 3 + k] = b.hi[k];
+        cur = parent_of_node[cur];
+    }
+}
+
+// The 64-byte records the path kernels walk: both child boxes and both links per internal node.
+__global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n, const int32_t* child0,
+                          const int32_t* child1, const float* node_box, Node64* out) {
+    const int i = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (i >= n - 1) return;
+    Box b[2];
+    int32_t link[2];
+    const int32_t c[2] = {child0[i], child1[i]};
+    for (int side = 0; side < 2; side++) {
+        if (c[side] < 0) {
+            const uint32_t pos = (uint32_t)~c[side];
+            b[side] = sphere_box(spheres[order[pos]]);
+            link[side] = (int32_t)~pos;  // leaf of one sphere: first = pos, count - 1 = 0
+        } else {
+            for (int k = 0; k < 3; k++) {
+                b[side].lo[k] = node_box[(size_t)c[side] * 6 + k];
+                b[side].hi[k] = node_box[(size_t)c[side] * 6 + 3 + k];
+            }
+            link[side] = c[side];
+        }
+    }
+    Node64 nd;
+    nd.q0 = f4{b[0].lo[0], b[0].lo[1], b[0].lo[2], b[0].hi[0]};
+    nd.q1 = f4{b[0].hi[1], b[0].hi[2], b[1].lo[0], b[1].lo[1]};
+    nd.q2 = f4{b[1].lo[2], b[1].hi[0], b[1].hi[1], b[1].hi[2]};
+    nd.child0 = link[0], nd.child1 = link[1];
+    nd.pad[0] = nd.pad[1] = 0u;
+    out[i] = nd;
+}
+
+// Spheres and their material words in leaf (= sorted) order; the tie rank is the sphere's index.
+__global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, uint32_t n, f4* out_spheres, u2* out_info) {
+    const uint32_t p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    const Sphere32 s = spheres[order[p]];
+    out_spheres[p] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad};
+    const uint32_t type = s.mat_type > 3u ? 4u : s.mat_type;
+    out_info[p] = u2{type | (s.mat_index << 3), order[p]};
+}
+
+struct Scratch {  // device allocations of one build, released on every exit path
+    std::vector<void*> ptrs;
+    ~Scratch() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <class T>
+    bool get(T** out, size_t count) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)) != hipSuccess) return false;
+        ptrs.push_back(p);
+        *out = static_cast<T*>(p);
+        return true;
+    }
+};
+
+}  // namespace
+
+bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std::string& err) {
+    if (!validate_scene(a, err)) return false;
+    const uint32_t n = (uint32_t)a.n_spheres;
+    PT_HIP(hipSetDevice(d->id));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    hipStream_t st = d->stream;
+
+    SceneLayout L = make_layout(a, n - 1u, false);
+    if (L.total_bytes == 0) {
+        err = "scene: device blob exceeds 4 GiB";
+        return false;
+    }
+    Scratch tmp;
+    Sphere32* spheres;
+    uint64_t *keys, *keys_sorted;
+    uint32_t *vals, *order;
+    int32_t *child0, *child1, *parent_of_node, *parent_of_leaf;
+    int *arrived, *box, *max_depth;
+    float* node_box;
+    if (!tmp.get(&spheres, n) || !tmp.get(&keys, n) || !tmp.get(&keys_sorted, n) || !tmp.get(&vals, n) ||
+        !tmp.get(&order, n) || !tmp.get(&child0, n) || !tmp.get(&child1, n) || !tmp.get(&parent_of_node, n) ||
+        !tmp.get(&parent_of_leaf, n) || !tmp.get(&arrived, n) || !tmp.get(&box, 8) || !tmp.get(&max_depth, 1) ||
+        !tmp.get(&node_box, (size_t)n * 6)) {
+        err = "lbvh: out of device memory";
+        return false;
+    }
+    size_t sort_bytes = 0;
+    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
+    char* sort_tmp;
+    if (!tmp.get(&sort_tmp, sort_bytes)) {
+        err = "lbvh: out of device memory";
+        return false;
+    }
+    const size_t bytes = ((size_t)L.total_bytes + 15u) & ~(size_t)15u;
+    if (bytes > d->scene_cap) {
+        (void)hipFree(d->scene);
+        d->scene = nullptr;
+        d->scene_cap = 0;
+        PT_HIP(hipMalloc(&d->scene, bytes));
+        d->scene_cap = bytes;
+    }
+    d->have_scene = false;
+
+    const int box_init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
+    PT_HIP(hipMemcpyAsync(spheres, a.spheres, (size_t)n * sizeof(Sphere32), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(box, box_init, sizeof box_init, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(arrived, 0, (size_t)n * sizeof(int), st));
+    PT_HIP(hipMemsetAsync(max_depth, 0, sizeof(int), st));
+    PT_HIP(hipMemsetAsync(d->scene, 0, bytes, st));
+    const dim3 grid((n + BLK - 1) / BLK), block(BLK);
+    hipLaunchKernelGGL(lbvh_bounds, grid, block, 0, st, spheres, n, box);
+    hipLaunchKernelGGL(lbvh_codes, grid, block, 0, st, spheres, n, box, keys, vals);
+    PT_HIP(hipGetLastError());
+    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
+    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, st, keys_sorted, (int)n, child0, child1, parent_of_node,
+                       parent_of_leaf);
+    hipLaunchKernelGGL(lbvh_refit, grid, block, 0, st, spheres, order, (int)n, child0, child1, parent_of_node,
+                       parent_of_leaf, arrived, node_box, max_depth);
+    hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box,
+                       reinterpret_cast<Node64*>(d->scene + L.off_nodes));
+    hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
+                       reinterpret_cast<u2*>(d->scene + L.off_info));
+    PT_HIP(hipGetLastError());
+    if (a.n_lights) PT_HIP(hipMemcpyAsync(d->scene + L.off_lights, a.lights, a.n_lights * 16, hipMemcpyHostToDevice, st));
+    if (a.n_lambertians)
+        PT_HIP(hipMemcpyAsync(d->scene + L.off_lambertians, a.lambertians, a.n_lambertians * 16, hipMemcpyHostToDevice, st));
+    if (a.n_metals) PT_HIP(hipMemcpyAsync(d->scene + L.off_metals, a.metals, a.n_metals * 16, hipMemcpyHostToDevice, st));
+    if (a.n_glass) PT_HIP(hipMemcpyAsync(d->scene + L.off_glass, a.glass, a.n_glass * 4, hipMemcpyHostToDevice, st));
+    int depth = 0;
+    PT_HIP(hipMemcpyAsync(&depth, max_depth, sizeof depth, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    L.max_depth = (uint32_t)std::max(1, depth);
+    layout = L;
+    return adopt_layout(d, L, err);
+}
+
+}  // namespace gpu
+}  // namespace pt

@@ -12,7 +12,7 @@
 static void usage() {
     fprintf(stderr,
             "usage: mi355pt_offline [--scene scene1.ron] [--settings settings.ron] [--width 1280] [--height 720]\n"
-            "                       [--frames 1000] [--seed N] [--device 0] [--bvh sah|reference] [--out img.png]\n"
+            "                       [--frames 1000] [--seed N] [--device 0] [--bvh sah|reference|lbvh] [--out img.png]\n"
             "                       [--chunk 50]\n");
 }
 
@@ -64,7 +64,7 @@ int main(int argc, char** argv) {
     mi355pt_desc desc;
     memset(&desc, 0, sizeof desc);
     desc.width = width, desc.height = height, desc.device = device, desc.base_seed = seed;
-    desc.bvh_mode = bvh == "reference" ? MI355PT_BVH_REFERENCE : MI355PT_BVH_SAH;
+    desc.bvh_mode = bvh == "reference" ? MI355PT_BVH_REFERENCE : (bvh == "lbvh" ? MI355PT_BVH_LBVH : MI355PT_BVH_SAH);
     mi355pt_ctx* ctx = nullptr;
     if (mi355pt_create(&desc, &ctx) != MI355PT_OK) {
         fprintf(stderr, "error: %s\n", mi355pt_last_error(nullptr));

@@ -111,6 +111,30 @@ bool validate_scene(const SceneArrays& a, std::string& err) {
     return true;
 }
 
+SceneLayout make_layout(const SceneArrays& a, uint32_t n_nodes, bool half_nodes) {
+    auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
+    const size_t n = a.n_spheres;
+    SceneLayout L{};
+    size_t off = 0;
+    L.off_nodes = (uint32_t)off, L.n_nodes = n_nodes;
+    off = align16(off + (size_t)n_nodes * (half_nodes ? sizeof(Node32) : sizeof(Node64)));
+    L.off_spheres = (uint32_t)off, L.n_spheres = (uint32_t)n;
+    off = align16(off + n * sizeof(f4));
+    L.off_info = (uint32_t)off;
+    off = align16(off + n * sizeof(u2));
+    L.off_lights = (uint32_t)off, L.n_lights = (uint32_t)a.n_lights;
+    off = align16(off + a.n_lights * 16);
+    L.off_lambertians = (uint32_t)off, L.n_lambertians = (uint32_t)a.n_lambertians;
+    off = align16(off + a.n_lambertians * 16);
+    L.off_metals = (uint32_t)off, L.n_metals = (uint32_t)a.n_metals;
+    off = align16(off + a.n_metals * 16);
+    L.off_glass = (uint32_t)off, L.n_glass = (uint32_t)a.n_glass;
+    off = align16(off + a.n_glass * 4);
+    L.total_bytes = off > 0xfffffff0ull ? 0u : (uint32_t)off;
+    L.node_half = half_nodes ? 1u : 0u;
+    return L;
+}
+
 bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref_nodes, size_t n_ref_nodes,
                 std::vector<char>& blob, SceneLayout& L, Bvh2& bvh, std::string& err) {
     if (!validate_scene(a, err)) return false;
@@ -170,27 +194,18 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     // A tree that stays in global memory is renumbered so that any prefix of the node array is the
     // most frequently visited top of the tree; the kernels keep such a prefix in LDS.
     if (!lds_with_float && !L.node_half) order_top_first(bvh, 4096);
-    size_t off = 0;
-    L.off_nodes = (uint32_t)off, L.n_nodes = (uint32_t)bvh.nodes.size();
-    off = align16(off + bvh.nodes.size() * (L.node_half ? sizeof(Node32) : sizeof(Node64)));
-    L.off_spheres = (uint32_t)off, L.n_spheres = n;
-    off = align16(off + (size_t)n * sizeof(f4));
-    L.off_info = (uint32_t)off;
-    off = align16(off + (size_t)n * sizeof(u2));
-    L.off_lights = (uint32_t)off, L.n_lights = (uint32_t)a.n_lights;
-    off = align16(off + a.n_lights * 16);
-    L.off_lambertians = (uint32_t)off, L.n_lambertians = (uint32_t)a.n_lambertians;
-    off = align16(off + a.n_lambertians * 16);
-    L.off_metals = (uint32_t)off, L.n_metals = (uint32_t)a.n_metals;
-    off = align16(off + a.n_metals * 16);
-    L.off_glass = (uint32_t)off, L.n_glass = (uint32_t)a.n_glass;
-    off = align16(off + a.n_glass * 4);
-    if (off > 0xfffffff0ull) {
-        err = "scene: device blob exceeds 4 GiB";
-        return false;
+    {
+        const SceneLayout sized = make_layout(a, (uint32_t)bvh.nodes.size(), L.node_half != 0);
+        if (sized.total_bytes == 0) {
+            err = "scene: device blob exceeds 4 GiB";
+            return false;
+        }
+        const float org[3] = {L.box_org[0], L.box_org[1], L.box_org[2]};
+        L = sized;
+        L.box_org[0] = org[0], L.box_org[1] = org[1], L.box_org[2] = org[2];
     }
-    L.total_bytes = (uint32_t)off;
     L.max_depth = bvh.max_depth;
+    const size_t off = L.total_bytes;
     blob.assign(off, 0);
     if (L.node_half) memcpy(blob.data() + L.off_nodes, half_nodes.data(), half_nodes.size() * sizeof(Node32));
     else memcpy(blob.data() + L.off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(Node64));

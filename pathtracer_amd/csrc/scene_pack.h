@@ -34,6 +34,10 @@ bool validate_scene(const SceneArrays& a, std::string& err);
 uint16_t half_floor(double x);
 uint16_t half_ceil(double x);
 
+// Section offsets of the device blob for a tree of n_nodes interior nodes (total_bytes = 0 when the blob
+// would exceed 4 GiB); max_depth and box_org are left for the caller.
+SceneLayout make_layout(const SceneArrays& a, uint32_t n_nodes, bool half_nodes);
+
 bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref_nodes, size_t n_ref_nodes,
                 std::vector<char>& blob, SceneLayout& layout, Bvh2& bvh, std::string& err);
 

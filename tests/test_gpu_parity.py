@@ -250,6 +250,36 @@ def test_large_scene_in_global_memory(pa, orc):
     assert bits_equal(ref[y0:y1, x0:x1], acc[y0:y1, x0:x1])
 
 
+@pytest.mark.parametrize("name", ["scene1", "scene2", "scene3"])
+def test_tree_built_on_the_gpu(pa, orc, name):
+    # Morton-order tree from lbvh.hip: another tree, the same image
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, name + ".ron"))
+    osc = oracle_scene(orc, sc)
+    W, H = 96, 54
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS, threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, SEEDS, bvh_mode=pa.BVH_LBVH, flags=pa.FLAG_COUNT)
+    assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
+    assert gs["bvh_nodes"] == len(sc.spheres) - 1 and gs["bvh_depth"] >= 1
+
+
+def test_tree_built_on_the_gpu_large(pa, orc):
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(200_000)
+    osc = oracle_scene(orc, sc)
+    W, H = 320, 180
+    crop = (96, 224, 60, 120)
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:2], crop=crop, threads=16)
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) as r:
+        r.render(seeds=SEEDS[:2])
+        acc, gs = r.read_accum(), r.stats()
+        r.reload_scene(sc)                      # rebuild on the device, same result
+        r.render(seeds=SEEDS[:2])
+        again = r.read_accum()
+    assert gs["scene_in_lds"] == 0 and gs["bvh_nodes"] == len(sc.spheres) - 1
+    x0, x1, y0, y1 = crop
+    assert bits_equal(ref[y0:y1, x0:x1], acc[y0:y1, x0:x1]) and bits_equal(acc, again)
+
+
 def test_half_precision_nodes_in_lds(pa, orc):
     # ~800 spheres fit the LDS budget only with 32-byte nodes; conservative boxes change no bit
     from pathtracer_amd import synth

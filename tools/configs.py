@@ -30,8 +30,12 @@ for name in sys.argv[1:] or ["c1", "c2", "c3a", "c3b"]:
     sc = pa.load_ron_scene(src) if isinstance(src, str) else synth.plane_scene(src)
     t_scene = time.time() - t0
     t0 = time.time()
-    r = pa.Renderer(sc, pa.Settings(1, 50), W, H)
+    bvh_mode = {"sah": pa.BVH_SAH, "reference": pa.BVH_REFERENCE, "lbvh": pa.BVH_LBVH}[os.environ.get("CFG_BVH", "sah")]
+    r = pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=bvh_mode)
     t_build = time.time() - t0
+    t0 = time.time()
+    r.reload_scene(sc)              # a second build: no first-use costs (allocations, code objects)
+    t_rebuild = time.time() - t0
     r.render(min(F, 16))           # warm-up (long enough to measure the tile costs once)
     r.clear()
     t0 = time.time()
@@ -39,14 +43,14 @@ for name in sys.argv[1:] or ["c1", "c2", "c3a", "c3b"]:
     wall = time.time() - t0
     s = r.stats()
     r.close()
-    rc = pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=pa.FLAG_COUNT)
+    rc = pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=pa.FLAG_COUNT, bvh_mode=bvh_mode)
     fc = min(F, 4)
     rc.render(fc)
     c = rc.stats()
     rc.close()
     k_ms = s["render_ms"]
     out = {"config": name, "spheres": int(len(sc.spheres)), "size": [W, H], "frames": F,
-           "scene_s": round(t_scene, 2), "create_s": round(t_build, 2), "wall_ms": round(wall * 1e3, 1),
+           "scene_s": round(t_scene, 2), "create_s": round(t_build, 2), "rebuild_s": round(t_rebuild, 3), "wall_ms": round(wall * 1e3, 1),
            "kernel_ms": round(k_ms, 2), "resolve_ms": round(s["resolve_ms"], 2),
            "Mpaths_s": round(s["paths"] / k_ms / 1e3, 1), "Mrays_s": round(s["rays"] / k_ms / 1e3, 1),
            "rays_per_path": round(s["rays"] / s["paths"], 3),
