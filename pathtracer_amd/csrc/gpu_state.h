@@ -39,6 +39,7 @@ struct Device {
     // Cost-ordered work: rays per tile of the last launch, tiles sorted by it, and what it was measured for
     float* tile_cost = nullptr;    // [tiles]
     uint32_t* tile_perm = nullptr; // [tiles]
+    uint16_t* rank_chunk = nullptr; // [tiles] chunk size for a chunk that starts in the tile of that rank
     bool perm_valid = false;
     Camera64 perm_cam{};
     int32_t perm_depth = 0, perm_samples = 0;

@@ -31,14 +31,16 @@ namespace gpu {
 // single address is a device-wide serial resource: with fixed 4-unit chunks it cost 10 % of a scene1
 // launch on MI355X (65 M atomics/s) and two thirds of a scene2 launch.  Chunks are therefore up to
 // RenderParams::chunk_max units while plenty of work is left and shrink towards the end of the queue,
-// where balance matters: chunk = what is left / (2 * waves), clamped to [1, chunk_max].  The host sets
+// where balance matters: chunk = what is left / (2 * waves), clamped to [1, chunk_max]; once tile costs
+// are known, a chunk is also limited to about 2 600 rays (rank_chunk), because the expensive tiles come
+// first and a 32-unit chunk of them keeps one wave busy for 6 ms.  The host sets
 // chunk_max to 32 for scenes in LDS and to 4 for scenes in global memory: there the waves should stay
 // close together in the image, so that the part of the tree they walk stays in the caches (10 M spheres
 // at 3840x2160: 13.0 ms per 8 frames with 4-unit chunks, 28 ms with 32-unit chunks).
-__device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t taken_to, float inv_two_waves,
+__device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t taken_to, float inv_share,
                                                        uint32_t chunk_max) {
     const uint32_t left = total - min(total, taken_to);
-    return max(1u, min(chunk_max, (uint32_t)((float)left * inv_two_waves)));
+    return max(1u, min(chunk_max, (uint32_t)((float)left * inv_share)));
 }
 
 #define PT_LDS(T) __attribute__((address_space(3))) T
@@ -132,6 +134,7 @@ struct RenderParams {
     uint32_t n_frames;
     float inv_n_frames;
     const uint32_t* tile_perm;
+    const uint16_t* rank_chunk;  // with tile_perm: chunk size by the rank the chunk starts in (cost-aware)
     const uint32_t* seeds;       // one per frame of this launch
     const uint32_t* pixel_hash;  // [n_pix]
     f4* frame_out;               // [frame][tile rank][slot]: rgb = final_colour / samples, w = rays traced
@@ -144,7 +147,7 @@ struct RenderParams {
                       // terminal, opaque, glass, idle
     float inv_tiles_x;
     uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
-    float inv_two_waves;  // 1 / (2 * waves in the grid), for the chunk size
+    float inv_share;  // 1 / (2 * waves in the grid), for the chunk size
     uint32_t chunk_max;
     // SCENE_GLOBAL only: scene_lds_bytes is the node prefix kept in LDS, the stack keeps
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
 
     // wave state (uniform)
     uint32_t next = 0, end = 0;
-    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_two_waves, P.chunk_max);
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_share, P.chunk_max);
     bool exhausted = false;
 
     for (;;) {
@@ -231,7 +234,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
                 }
                 next = base * 64u;
                 end = min(base + chunk, P.total_units) * 64u;
-                chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_two_waves, P.chunk_max);
+                chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_share, P.chunk_max);
             }
             const uint32_t avail = end - next;
             const uint32_t rank = lane_rank(m);
@@ -378,7 +381,8 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     uint32_t ph_exec[PH_COUNT] = {0}, ph_lanes[PH_COUNT] = {0};  // COUNT: wave-level step executions
 
     uint32_t next = 0, end = 0;  // wave-uniform: the wave's chunk of the path queue
-    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_two_waves, P.chunk_max);
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_share, P.chunk_max);
+    if (P.rank_chunk) chunk = min(chunk, (uint32_t)P.rank_chunk[0]);
     bool exhausted = false;
     bool force = false;
 
@@ -503,7 +507,15 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                     }
                     next = base * 64u;
                     end = min(base + chunk, P.total_units) * 64u;
-                    chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_two_waves, P.chunk_max);
+                    {
+                        const uint32_t taken_to = base + chunk;
+                        chunk = guided_chunk_units(P.total_units, taken_to, P.inv_share, P.chunk_max);
+                        if (P.rank_chunk && taken_to < P.total_units) {
+                            // about where the queue will stand at this wave's next visit
+                            const uint32_t r = min(P.tiles_per_frame - 1u, (uint32_t)((float)taken_to * P.inv_n_frames));
+                            chunk = min(chunk, (uint32_t)P.rank_chunk[r]);
+                        }
+                    }
                 }
                 const uint32_t avail = end - next;
                 const uint32_t rank = lane_rank(m);
@@ -622,7 +634,11 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
 // workgroup, a 256-bucket counting sort.  Ties land in arbitrary order, which nothing depends on.
 constexpr int ORDER_BLK = 1024;
-__global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm) {
+// rank_chunk[r]: units a chunk starting in the r-th tile of that order should hold so that it costs about
+// `chunk_rays` rays (the cost of one unit of a tile = its measured rays / frames_measured).
+__global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm,
+                                                                 uint16_t* rank_chunk, float frames_measured,
+                                                                 float chunk_rays, uint32_t chunk_max) {
     __shared__ uint32_t hist[256];
     __shared__ float red[ORDER_BLK];
     float mx = 0.0f;
@@ -647,7 +663,13 @@ __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* t
         }
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) perm[atomicAdd(&hist[bucket(tile_cost[t])], 1u)] = t;
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) {
+        const float c = tile_cost[t];
+        const uint32_t r = atomicAdd(&hist[bucket(c)], 1u);
+        perm[r] = t;
+        const float unit_rays = fmaxf(c / frames_measured, 1.0f);
+        rank_chunk[r] = (uint16_t)max(1u, min(chunk_max, (uint32_t)(chunk_rays / unit_rays)));
+    }
 }
 
 __global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
@@ -710,6 +732,7 @@ void destroy(Device* d) {
     (void)hipFree(d->frame_buf);
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
+    (void)hipFree(d->rank_chunk);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
@@ -786,6 +809,8 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     (void)hipFree(d->pixel_hash);
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
+    (void)hipFree(d->rank_chunk);
+    d->rank_chunk = nullptr;
     d->accum = nullptr;
     d->pixel_hash = nullptr;
     d->tile_cost = nullptr, d->tile_perm = nullptr;
@@ -795,6 +820,7 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     PT_HIP(hipMalloc(&d->pixel_hash, (size_t)n_pix * sizeof(uint32_t)));
     PT_HIP(hipMalloc(&d->tile_cost, n_tiles * sizeof(float)));
     PT_HIP(hipMalloc(&d->tile_perm, n_tiles * sizeof(uint32_t)));
+    PT_HIP(hipMalloc(&d->rank_chunk, n_tiles * sizeof(uint16_t)));
     d->width = width, d->height = height, d->n_pix = n_pix;
     hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
                        height);
@@ -854,7 +880,10 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
     uint32_t max_blocks = (P.total_units + (BLK / 64) - 1u) / (BLK / 64);
     grid = std::max(1u, std::min(grid, max_blocks));
     RenderParams Q = P;
-    Q.inv_two_waves = 1.0f / (2.0f * (float)grid * (float)(BLK / 64));
+    // MI355PT_CHUNK_SHARE (development switch): chunks are at most 1/share of an even split of what is left
+    const char* senv = getenv("MI355PT_CHUNK_SHARE");
+    const float share = senv && atof(senv) > 0.0 ? (float)atof(senv) : 2.0f;
+    Q.inv_share = 1.0f / (share * (float)grid * (float)(BLK / 64));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, Q);
     PT_HIP(hipGetLastError());
     return true;
@@ -1099,6 +1128,10 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         return false;
     }
 
+    // Rays a chunk should cost: a wave traces about 6.5 M rays/s, so 2 600 rays are 400 us per chunk and
+    // 6 144 waves issue 15 M queue atomics/s.  MI355PT_CHUNK_RAYS overrides (development switch).
+    float chunk_rays = 2600.0f;
+    if (const char* e = getenv("MI355PT_CHUNK_RAYS")) chunk_rays = std::max(64.0f, (float)atof(e));
     // MI355PT_TILE_ORDER=0 keeps row-major tile order (development switch)
     const char* tenv = getenv("MI355PT_TILE_ORDER");
     const bool order_tiles = !(tenv && atoi(tenv) == 0);
@@ -1111,6 +1144,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         P.n_frames = nb;
         P.inv_n_frames = 1.0f / (float)nb;
         P.tile_perm = use_perm ? d->tile_perm : nullptr;
+        P.rank_chunk = use_perm ? d->rank_chunk : nullptr;
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = dev_seeds + f0;
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
@@ -1135,7 +1169,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         PT_HIP(hipGetLastError());
         if (measure) {
             hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(ORDER_BLK), 0, d->stream, d->tile_cost, tiles,
-                               d->tile_perm);
+                               d->tile_perm, d->rank_chunk, (float)nb, chunk_rays, P.chunk_max);
             PT_HIP(hipGetLastError());
             d->perm_valid = true;
             d->perm_cam = cam;
