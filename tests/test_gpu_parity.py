@@ -262,6 +262,26 @@ def test_tree_built_on_the_gpu(pa, orc, name):
     assert gs["bvh_nodes"] == len(sc.spheres) - 1 and gs["bvh_depth"] >= 1
 
 
+def test_tree_built_on_the_gpu_edge_cases(pa, orc):
+    # two spheres (one interior node); many spheres at one position (equal Morton codes, ties by index);
+    # the default scene (4 spheres, one of them the 1000-radius ground)
+    W, H = 64, 48
+    two = pa.Scene.default()
+    two.spheres = two.spheres[:2].copy()
+    same = pa.Scene.default()
+    sp = np.zeros(4 + 40, pa.renderer.SPHERE_DT)
+    sp[:4] = same.spheres
+    sp[4:] = same.spheres[1]                       # 40 coincident copies of one sphere
+    sp[4:]["rad"] = np.linspace(0.05, 0.45, 40).astype(np.float32)   # nested, so no equal roots
+    same.spheres = sp
+    for sc in (two, same, pa.Scene.default()):
+        osc = oracle_scene(orc, sc)
+        ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:3])
+        acc, gs = gpu_render(pa, sc, W, H, SEEDS[:3], bvh_mode=pa.BVH_LBVH)
+        assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
+        assert gs["bvh_nodes"] == len(sc.spheres) - 1
+
+
 def test_tree_built_on_the_gpu_large(pa, orc):
     from pathtracer_amd import synth
     sc = synth.plane_scene(200_000)
