@@ -4,7 +4,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <future>
 #include <limits>
+#include <thread>
 #include <queue>
 #include <utility>
 #include <vector>
@@ -230,7 +232,11 @@ struct SahBuilder {
     std::vector<Prim> prims;
     std::vector<TmpNode> tmp;
 
-    int32_t build(uint32_t lo, uint32_t hi, uint32_t depth, bool force_split) {
+    // Builds the subtree over prims[lo, hi) into `tmp` (pre-order) and returns its index there.  The
+    // first `fork_levels` levels of large ranges build their right halves on other threads, each into
+    // its own vector that is appended afterwards: same tree, same node order as the serial build.
+    int32_t build(std::vector<TmpNode>& tmp, uint32_t lo, uint32_t hi, uint32_t depth, bool force_split,
+                  int fork_levels) {
         TmpNode node;
         node.box = empty_box();
         Box cb = empty_box();
@@ -321,8 +327,23 @@ struct SahBuilder {
             std::nth_element(prims.begin() + lo, prims.begin() + mid, prims.begin() + hi,
                              [axis](const Prim& x, const Prim& y) { return x.c[axis] < y.c[axis]; });
         }
-        int32_t l = build(lo, mid, depth + 1, false);
-        int32_t r = build(mid, hi, depth + 1, false);
+        if (fork_levels > 0 && n >= (1u << 16)) {
+            std::vector<TmpNode> right_nodes;
+            auto right = std::async(std::launch::async, [&, mid, hi, depth, fork_levels]() {
+                return build(right_nodes, mid, hi, depth + 1, false, fork_levels - 1);
+            });
+            int32_t l = build(tmp, lo, mid, depth + 1, false, fork_levels - 1);
+            int32_t r = right.get();
+            const int32_t shift = (int32_t)tmp.size();
+            for (TmpNode& t : right_nodes)
+                if (t.count == 0) t.left += shift, t.right += shift;
+            tmp.insert(tmp.end(), right_nodes.begin(), right_nodes.end());
+            tmp[me].left = l;
+            tmp[me].right = r + shift;
+            return me;
+        }
+        int32_t l = build(tmp, lo, mid, depth + 1, false, 0);
+        int32_t r = build(tmp, mid, hi, depth + 1, false, 0);
         tmp[me].left = l;
         tmp[me].right = r;
         return me;
@@ -421,7 +442,10 @@ bool build_sah(const Sphere32* spheres, uint32_t n, Bvh2& out, std::string& err)
         p.id = i;
     }
     b.tmp.reserve(2ull * n);
-    int32_t root = b.build(0, n, 0, true);
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    int fork_levels = 0;  // 2^levels concurrent subtrees, about as many as there are cores (at most 32)
+    while ((1u << fork_levels) < std::min(hw, 32u)) fork_levels++;
+    int32_t root = b.build(b.tmp, 0, n, 0, true, fork_levels);
     out.nodes.reserve(n);
     out.order.reserve(n);
     b.emit(root, 0, out);
