@@ -300,6 +300,7 @@ int main(int argc, char** argv) {
     camera_build(sc.camera.pos, sc.camera.yaw, sc.camera.pitch, sc.camera.vfov, (float)W / (float)H, cam64);
     CameraRegs cam = load_camera(cam64);
 
+    const bool real_postpone = argc > 5 && !strcmp(argv[5], "postpone2");
     // trace every path of two frames in the kernel's queue order (8x8 tiles, row-major tiles)
     std::vector<Path> paths;
     const uint32_t tiles_x = (W + 7) / 8, tiles_y = (H + 7) / 8;
@@ -320,6 +321,29 @@ int main(int argc, char** argv) {
                     Walk w;
                     Counters cnt = {0, 0, 0};
                     walk_begin<false>(w, L, ps.o, ps.d);
+                    if (real_postpone) {
+                        // a lane holds one leaf and keeps walking until it meets the next leaf or the end
+                        int32_t pend = 0;  // 0 = none (leaf links are negative)
+                        auto flush = [&]() {
+                            const uint32_t ref = ~(uint32_t)pend, first = ref & LEAF_FIRST_MASK, count = (ref >> LEAF_COUNT_SHIFT) + 1u;
+                            for (uint32_t k = 0; k < count; k++)
+                                walk_test_sphere<PtrMem, false>(mem, L, w, ps.o, ps.d, first + k, cnt), sg.steps += 'L';
+                            pend = 0;
+                        };
+                        for (;;) {
+                            if (w.cur == WALK_FINISHED) {
+                                if (pend) flush();
+                                break;
+                            }
+                            if (walk_is_node(w.cur)) {
+                                walk_node<PtrMem, HostStack, false, false>(mem, L, st, w, cnt), sg.steps += 'N';
+                            } else {
+                                if (pend) flush();
+                                pend = w.cur;
+                                walk_pop(w, st);
+                            }
+                        }
+                    } else
                     while (w.cur != WALK_FINISHED) {
                         if (walk_is_node(w.cur)) walk_node<PtrMem, HostStack, false, false>(mem, L, st, w, cnt), sg.steps += 'N';
                         else walk_leaf_one<PtrMem, HostStack, false>(mem, L, st, w, ps.o, ps.d, cnt), sg.steps += 'L';
