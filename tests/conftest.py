@@ -106,3 +106,39 @@ def oracle_scene(orc, scene, **kw):
 def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a, np.float32).view(np.uint32),
                           np.ascontiguousarray(b, np.float32).view(np.uint32))
+
+
+def random_scene(pa, seed, duplicates=True):
+    """A small random scene that leans on the awkward cases: overlapping and nested spheres, the camera
+    possibly inside one, exact duplicates (equal roots), glass with ir below, at and above 1, mirror and
+    fully rough metals, bright lights, now and then a material type the shader does not know."""
+    from pathtracer_amd.renderer import SPHERE_DT, VEC16_DT, CameraSettings, Scene
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(2, 60))
+    sp = np.zeros(n, SPHERE_DT)
+    sp["pos"] = rng.uniform((-6, -1, -6), (6, 3, 6), (n, 3)).astype(np.float32)
+    sp["rad"] = rng.choice([0.05, 0.3, 0.5, 1.0, 1.5, 4.0], n, p=[.1, .3, .3, .15, .1, .05]).astype(np.float32)
+    if rng.random() < 0.7:                                   # a ground sphere, as in every shipped scene
+        sp[0] = ((0.0, -1000.0, 0.0), 1000.0, 1, 0, (0, 0))
+    counts = rng.integers(1, 6, 4)
+    sp["mat_type"] = rng.integers(0, 4, n)
+    sp["mat_index"] = [rng.integers(0, counts[t]) for t in sp["mat_type"]]
+    unknown = rng.random(n) < 0.03
+    sp["mat_type"][unknown] = 9                              # compute.wgsl:356-358 -> black
+    if duplicates and n >= 4:
+        k = int(rng.integers(1, 4))
+        src, dst = rng.integers(0, n, k), rng.integers(1, n, k)
+        for a, b in zip(src, dst):                           # same ball, usually another material
+            sp["pos"][b], sp["rad"][b] = sp["pos"][a], sp["rad"][a]
+    lights = np.zeros(counts[0], VEC16_DT)
+    lights["v"] = rng.uniform(0.5, 6.0, (counts[0], 3)).astype(np.float32)
+    lam = np.zeros(counts[1], VEC16_DT)
+    lam["v"] = rng.uniform(0.0, 1.0, (counts[1], 3)).astype(np.float32)
+    met = np.zeros(counts[2], VEC16_DT)
+    met["v"] = rng.uniform(0.2, 1.0, (counts[2], 3)).astype(np.float32)
+    met["w"] = rng.choice([0.0, 0.1, 0.5, 1.0], counts[2]).astype(np.float32)
+    gla = rng.choice([0.7, 1.0, 1.01, 1.5, 2.4], counts[3]).astype(np.float32)
+    cam = CameraSettings(tuple(rng.uniform((-8, 0, -8), (8, 4, 8)).astype(np.float32)),
+                         np.float32(rng.uniform(-180, 180)), np.float32(rng.uniform(-40, 20)),
+                         np.float32(rng.choice([20.0, 45.0, 70.0, 90.0])))
+    return Scene(cam, sp, lights, lam, met, gla)

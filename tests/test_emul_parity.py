@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import FIXTURES, bits_equal, oracle_scene
+from conftest import FIXTURES, bits_equal, oracle_scene, random_scene
 
 SEEDS = [0x00C0FFEE, 0x12345678, 7]
 
@@ -214,3 +214,16 @@ def test_top_first_node_order_is_the_same_tree(emul, pa, k_top):
     sc = synth.plane_scene(5000)
     rc = emul.emul_check_top_first(C.c_void_p(sc.spheres.ctypes.data), C.c_size_t(len(sc.spheres)), C.c_uint32(min(k_top, 2 ** 32 - 1)))
     assert rc == 0
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes(emul, orc, pa, seed):
+    sc = random_scene(pa, 1000 + seed)
+    osc = oracle_scene(orc, sc)
+    W, H = 40, 24
+    cam = osc.camera(W, H)
+    samples, depth = (1, 50) if seed % 3 else (2, 6)
+    ref, st = orc.render(osc, cam, W, H, SEEDS[:2], samples=samples, depth=depth, threads=4)
+    for topo in (0, 1):
+        acc, cnt, _ = emul.render(sc, cam, W, H, SEEDS[:2], samples=samples, depth=depth, ref_topo=topo)
+        assert bits_equal(ref, acc) and cnt["rays"] == st["rays"]
