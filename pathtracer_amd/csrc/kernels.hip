@@ -47,6 +47,7 @@ __device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t 
 
 // Scene blob staged in LDS: explicit address space so every fetch is a ds_read.
 struct LdsMem {
+    static constexpr bool ORDERED_NODES = false;
     uint32_t base;
     template <class T>
     __device__ __forceinline__ T load(uint32_t off) const {
@@ -70,10 +71,28 @@ struct LdsMem {
     }
     __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
+// The same with the node section replaced by direction-ordered 80-byte records (LDS_NODE_BYTES) at
+// `node_base`; `base` is shifted so that the blob offsets of the other sections still apply.
+struct LdsOrderedMem : LdsMem {
+    static constexpr bool ORDERED_NODES = true;
+    uint32_t node_base;
+    __device__ __forceinline__ void node_ordered(uint32_t node, const uint32_t* sgn, f4& ax, f4& ay, f4& az, u2& ch) const {
+        typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+        const uint32_t a = node_base + __umul24(node, LDS_NODE_BYTES);  // node < 2^24: the scene fits LDS
+        auto four = [](uint32_t addr) {  // 8-byte aligned: two halves, merged into one ds_read2_b64
+            const w2 lo = *reinterpret_cast<const PT_LDS(w2)*>(addr), hi = *reinterpret_cast<const PT_LDS(w2)*>(addr + 8u);
+            return f4{__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+        };
+        ax = four(a + sgn[0]), ay = four(a + 24u + sgn[1]), az = four(a + 48u + sgn[2]);
+        const w2 c = *reinterpret_cast<const PT_LDS(w2)*>(a + 72u);
+        ch = u2{c.x, c.y};
+    }
+};
 // Scene blob in global memory with the first `lds_node_bytes` of the node array (the top of the
 // tree, see order_top_first) also staged in LDS.  Random record fetches from LDS sustain more than
 // twice the rate of fetches that hit in the vector L1, and the two pipes work side by side.
 struct HybridMem {
+    static constexpr bool ORDERED_NODES = false;
     const char* base;
     uint32_t lds_base;
     uint32_t lds_node_bytes;
@@ -171,25 +190,57 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // SCENE: where the scene blob is read from and which node format it holds.
 enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2 };
+template <int SCENE> struct SceneMem { typedef HybridMem type; };
+template <> struct SceneMem<SCENE_LDS> { typedef LdsOrderedMem type; };
+template <> struct SceneMem<SCENE_LDS_HALF> { typedef LdsMem type; };
+
+// Copies what the workgroup keeps in LDS: the whole blob (LDS scenes; float nodes become
+// direction-ordered 80-byte records on the way) or the node prefix (global scenes).
+template <int SCENE, int BLK>
+__device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0) {
+    typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+    typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+    const w4* src = reinterpret_cast<const w4*>(P.scene);
+    if constexpr (SCENE == SCENE_LDS) {
+        const uint32_t n = P.L.n_nodes;  // the node section starts the blob
+        for (uint32_t i = threadIdx.x; i < n; i += BLK) {
+            const w4 q0 = src[i * 4u], q1 = src[i * 4u + 1u], q2 = src[i * 4u + 2u], q3 = src[i * 4u + 3u];
+            const uint32_t lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+            const uint32_t lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+            const uint32_t a = lds0 + i * LDS_NODE_BYTES;
+#pragma unroll
+            for (uint32_t k = 0; k < 3; k++) {
+                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k) = w2{lo0[k], lo1[k]};
+                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 8u) = w2{hi0[k], hi1[k]};
+                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 16u) = w2{lo0[k], lo1[k]};
+            }
+            *reinterpret_cast<PT_LDS(w2)*>(a + 72u) = w2{q3.x, q3.y};
+        }
+        const uint32_t rest = (P.scene_lds_bytes - n * LDS_NODE_BYTES) / 16u;
+        for (uint32_t i = threadIdx.x; i < rest; i += BLK)
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + n * LDS_NODE_BYTES + i * 16u) = src[n * 4u + i];
+    } else {
+        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
+    }
+    __syncthreads();
+}
 
 template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
-    {   // the whole blob (LDS scenes) or the node prefix (global scenes)
-        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
-        const w4* src = reinterpret_cast<const w4*>(P.scene);
-        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
-            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
-        __syncthreads();
-    }
-    using Mem = typename std::conditional<LDS_SCENE, LdsMem, HybridMem>::type;
+    stage_scene<SCENE, BLK>(P, lds0);
+    using Mem = typename SceneMem<SCENE>::type;
     using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
     Mem mem;
     Stack stack;
     stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
-    if constexpr (LDS_SCENE) {
+    if constexpr (SCENE == SCENE_LDS) {
+        mem.node_base = lds0;
+        mem.base = lds0 + P.L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+    } else if constexpr (LDS_SCENE) {
         mem.base = lds0;
     } else {
         mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
@@ -339,19 +390,16 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
-    {   // the whole blob (LDS scenes) or the node prefix (global scenes)
-        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
-        const w4* src = reinterpret_cast<const w4*>(P.scene);
-        for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
-            *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
-        __syncthreads();
-    }
-    using Mem = typename std::conditional<LDS_SCENE, LdsMem, HybridMem>::type;
+    stage_scene<SCENE, BLK>(P, lds0);
+    using Mem = typename SceneMem<SCENE>::type;
     using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
     Mem mem;
     Stack stack;
     stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
-    if constexpr (LDS_SCENE) {
+    if constexpr (SCENE == SCENE_LDS) {
+        mem.node_base = lds0;
+        mem.base = lds0 + P.L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+    } else if constexpr (LDS_SCENE) {
         mem.base = lds0;
     } else {
         mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
@@ -782,11 +830,10 @@ bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::s
 }
 
 bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
-    const size_t bytes = ((size_t)layout.total_bytes + 15u) & ~(size_t)15u;
     d->layout = layout;
     d->have_scene = true;
     d->perm_valid = false;
-    d->scene_in_lds = bytes + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
+    d->scene_in_lds = lds_scene_bytes(layout) + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
         d->have_scene = false;
@@ -1073,7 +1120,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     };
     const long benv = env_int("MI355PT_BLOCK", 0);
     if (in_lds) {
-        P.scene_lds_bytes = (uint32_t)(((size_t)d->layout.total_bytes + 15u) & ~(size_t)15u);
+        P.scene_lds_bytes = lds_scene_bytes(d->layout);
         // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
         // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
         // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.

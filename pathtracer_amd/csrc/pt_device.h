@@ -153,6 +153,7 @@ PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, f
 // The scene blob is read through a view so the same code serves a blob staged in LDS, a blob in
 // global memory, and a host buffer.
 struct PtrMem {
+    static constexpr bool ORDERED_NODES = false;  // true: the view serves direction-ordered node records
     const char* base;
     template <class T>
     PT_FN T load(uint32_t byte_off) const {
@@ -204,6 +205,7 @@ struct Walk {
     bool best_back;
     int32_t cur;       // >= 0 interior node to visit; leaf link (see walk_is_leaf); or WALK_FINISHED
     int32_t sp;        // entries on the traversal stack
+    uint32_t sgn[3];   // 8 where the direction component is negative, else 0 (direction-ordered nodes)
 };
 // Leaf links are ~(first | (count-1) << 28) and lie in [-2^30, -1]; values below are free for
 // the walk's end marker and for the kernels' own lane states.
@@ -221,6 +223,7 @@ PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d) {
     if (fabsf(dc.y) < 1e-20f) dc.y = copysignf(1e-20f, dc.y);
     if (fabsf(dc.z) < 1e-20f) dc.z = copysignf(1e-20f, dc.z);
     w.inv = mk(PT_RCP(dc.x), PT_RCP(dc.y), PT_RCP(dc.z));
+    w.sgn[0] = dc.x < 0.0f ? 8u : 0u, w.sgn[1] = dc.y < 0.0f ? 8u : 0u, w.sgn[2] = dc.z < 0.0f ? 8u : 0u;
     if (HALF) o = o - mk(L.box_org[0], L.box_org[1], L.box_org[2]);  // half boxes are relative to box_org
     w.ood = mk(o.x * w.inv.x, o.y * w.inv.y, o.z * w.inv.z);
     w.best_t = INFINITY;
@@ -267,7 +270,23 @@ PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
     float t0, t1;
     bool h0, h1;
     int32_t c0, c1;
-    if constexpr (HALF) {
+    if constexpr (Mem::ORDERED_NODES) {
+        // per axis (near0, near1, far0, far1): the record is read from where the ray's sign puts the
+        // near planes first, so the slab test needs no min / max per axis
+        f4 ax, ay, az;
+        u2 ch;
+        mem.node_ordered((uint32_t)w.cur, w.sgn, ax, ay, az, ch);
+        t0 = fmaxf(fmaxf(PT_FMA(ax.x, w.inv.x, -w.ood.x), PT_FMA(ay.x, w.inv.y, -w.ood.y)),
+                   fmaxf(PT_FMA(az.x, w.inv.z, -w.ood.z), 0.0f));
+        t1 = fmaxf(fmaxf(PT_FMA(ax.y, w.inv.x, -w.ood.x), PT_FMA(ay.y, w.inv.y, -w.ood.y)),
+                   fmaxf(PT_FMA(az.y, w.inv.z, -w.ood.z), 0.0f));
+        const float f0 = fminf(fminf(PT_FMA(ax.z, w.inv.x, -w.ood.x), PT_FMA(ay.z, w.inv.y, -w.ood.y)),
+                               fminf(PT_FMA(az.z, w.inv.z, -w.ood.z), w.best_t));
+        const float f1 = fminf(fminf(PT_FMA(ax.w, w.inv.x, -w.ood.x), PT_FMA(ay.w, w.inv.y, -w.ood.y)),
+                               fminf(PT_FMA(az.w, w.inv.z, -w.ood.z), w.best_t));
+        h0 = t0 <= f0, h1 = t1 <= f1;
+        c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
+    } else if constexpr (HALF) {
         uint32_t off = L.off_nodes + (uint32_t)w.cur * 32u;
         u4 a, b;
         mem.node32(off, a, b);

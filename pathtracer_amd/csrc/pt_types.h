@@ -100,5 +100,14 @@ struct SceneLayout {
 // A scene whose blob plus the traversal stacks of a 256-lane workgroup stays within this budget is
 // staged in LDS by every workgroup (two or more workgroups per CU still fit).
 constexpr uint32_t LDS_SCENE_LIMIT = 64u * 1024u;
+// In LDS a Node64 is kept as an 80-byte record whose planes are laid out per axis as
+// (lo0, lo1, hi0, hi1, lo0, lo1): a ray reads four consecutive floats starting at the first or the
+// third, by the sign of its direction on that axis, and gets (near0, near1, far0, far1) without any
+// min / max.  The kernels convert while they stage the scene; the blob itself keeps Node64.
+constexpr uint32_t LDS_NODE_BYTES = 80u;
+inline uint32_t lds_scene_bytes(const SceneLayout& L) {
+    const uint32_t blob = (L.total_bytes + 15u) & ~15u;
+    return L.node_half ? blob : blob + L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+}
 
 }  // namespace pt
