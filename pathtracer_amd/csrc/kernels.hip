@@ -49,6 +49,7 @@ __device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t 
 struct LdsMem {
     static constexpr bool ORDERED_NODES = false;
     uint32_t base;
+    __device__ __forceinline__ int32_t root() const { return 0; }
     template <class T>
     __device__ __forceinline__ T load(uint32_t off) const {
         // address-space-qualified loads exist for builtin vector types only; bit-cast to the record
@@ -72,13 +73,15 @@ struct LdsMem {
     __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
 // The same with the node section replaced by direction-ordered 80-byte records (LDS_NODE_BYTES) at
-// `node_base`; `base` is shifted so that the blob offsets of the other sections still apply.
+// `node_base`; `base` is shifted so that the blob offsets of the other sections still apply.  Links to
+// interior nodes are the LDS byte addresses of their records (stage_scene rewrites them), which saves
+// the address arithmetic per visit; LDS addresses are small positive numbers, leaf links stay negative.
 struct LdsOrderedMem : LdsMem {
     static constexpr bool ORDERED_NODES = true;
     uint32_t node_base;
-    __device__ __forceinline__ void node_ordered(uint32_t node, const uint32_t* sgn, f4& ax, f4& ay, f4& az, u2& ch) const {
+    __device__ __forceinline__ int32_t root() const { return (int32_t)node_base; }
+    __device__ __forceinline__ void node_ordered(uint32_t a, const uint32_t* sgn, f4& ax, f4& ay, f4& az, u2& ch) const {
         typedef uint32_t w2 __attribute__((ext_vector_type(2)));
-        const uint32_t a = node_base + __umul24(node, LDS_NODE_BYTES);  // node < 2^24: the scene fits LDS
         auto four = [](uint32_t addr) {  // 8-byte aligned: two halves, merged into one ds_read2_b64
             const w2 lo = *reinterpret_cast<const PT_LDS(w2)*>(addr), hi = *reinterpret_cast<const PT_LDS(w2)*>(addr + 8u);
             return f4{__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
@@ -94,6 +97,7 @@ struct LdsOrderedMem : LdsMem {
 struct HybridMem {
     static constexpr bool ORDERED_NODES = false;
     const char* base;
+    __device__ __forceinline__ int32_t root() const { return 0; }
     uint32_t lds_base;
     uint32_t lds_node_bytes;
     template <class T>
@@ -214,7 +218,9 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
                 *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 8u) = w2{hi0[k], hi1[k]};
                 *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 16u) = w2{lo0[k], lo1[k]};
             }
-            *reinterpret_cast<PT_LDS(w2)*>(a + 72u) = w2{q3.x, q3.y};
+            const uint32_t l0 = (int32_t)q3.x >= 0 ? lds0 + q3.x * LDS_NODE_BYTES : q3.x;
+            const uint32_t l1 = (int32_t)q3.y >= 0 ? lds0 + q3.y * LDS_NODE_BYTES : q3.y;
+            *reinterpret_cast<PT_LDS(w2)*>(a + 72u) = w2{l0, l1};
         }
         const uint32_t rest = (P.scene_lds_bytes - n * LDS_NODE_BYTES) / 16u;
         for (uint32_t i = threadIdx.x; i < rest; i += BLK)
@@ -514,7 +520,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (scatter_opaque(mem, P.L, hit, mbits, ps, P.depth, radiance)) {
                     finish_sample(radiance);
                 } else {
-                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
                     rays++;
                 }
             }
@@ -529,7 +535,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (scatter_glass(mem, P.L, hit, mbits, ps, P.depth, P.glass_always_draws != 0, radiance)) {
                     finish_sample(radiance);
                 } else {
-                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
                     rays++;
                 }
             }
@@ -602,7 +608,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                     ps.o = cam.pos;
                     ps.colour = mk(1.0f, 1.0f, 1.0f);
                     ps.bounce = 0;
-                    walk_begin<HALF>(w, P.L, ps.o, ps.d);
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
                     rays++;
                 } else {
                     w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
@@ -1096,7 +1102,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
     P.inv_tiles_x = 1.0f / (float)tiles_x;
-    const uint32_t default_thr[6] = {16, 8, 24, 24, 8, 40};
+    const uint32_t default_thr[6] = {16, 8, 24, 16, 8, 40};
     for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {
         unsigned t[6];

@@ -155,6 +155,7 @@ PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, f
 struct PtrMem {
     static constexpr bool ORDERED_NODES = false;  // true: the view serves direction-ordered node records
     const char* base;
+    PT_FN int32_t root() const { return 0; }  // link of node 0
     template <class T>
     PT_FN T load(uint32_t byte_off) const {
         return *reinterpret_cast<const T*>(base + byte_off);
@@ -214,7 +215,7 @@ PT_FN bool walk_is_node(int32_t cur) { return cur >= 0; }
 PT_FN bool walk_is_leaf(int32_t cur) { return (uint32_t)cur >= 0xC0000000u; }
 
 template <bool HALF>
-PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d) {
+PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d, int32_t root = 0) {
     // Tiny direction components are clamped so no inf/NaN enters the box arithmetic; the
     // reciprocal may be approximate.  Neither reaches a pixel value: boxes only cull, and every
     // box carries the reference's 0.01 padding.
@@ -229,7 +230,7 @@ PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d) {
     w.best_t = INFINITY;
     w.best_idx = -1;
     w.best_back = false;
-    w.cur = 0;  // a scene has >= 2 spheres, so node 0 is interior
+    w.cur = root;  // a scene has >= 2 spheres, so node 0 is interior; `root` is its link in the view's terms
     w.sp = 0;
 }
 
@@ -381,7 +382,7 @@ template <class Mem, class Stack, bool COUNT, bool HALF>
 PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
                        Counters& cnt) {
     Walk w;
-    walk_begin<HALF>(w, L, o, d);
+    walk_begin<HALF>(w, L, o, d, mem.root());
     for (;;) {
         while (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT, HALF>(mem, L, stack, w, cnt);
         if (w.cur == WALK_FINISHED) break;
