@@ -51,8 +51,53 @@ PT_FN V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
 PT_FN V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 PT_FN V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
 PT_FN float dot3(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+// Correctly rounded sqrt(x), 1 / x and 1 / sqrt(x) (the latter rounded twice, like the expression).
+// On the device the compiler's general expansions spend a third of their instructions on operands
+// that never occur here (denormal scaling, infinities); these versions run the same refinement
+// without it whenever every active lane of the wave has an ordinary operand, and the general
+// expansion otherwise.  tests/hip/exact_check.hip compares them with the general expansions over all
+// 2^32 bit patterns.
+#ifndef PT_RCP_STEPS
+#define PT_RCP_STEPS 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_FN float sqrt_fast_body(float x) {  // 2^-96 <= x < inf
+    const float s = __builtin_amdgcn_sqrtf(x);  // within 1 ulp
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    return r_up > 0.0f ? s_up : r;
+}
+PT_FN float rcp_fast_body(float x) {  // 2^-100 <= x < 2^100
+    float y = __builtin_amdgcn_rcpf(x);  // within 1 ulp
+    float e = __builtin_fmaf(-x, y, 1.0f);
+    y = __builtin_fmaf(y, e, y);
+#if PT_RCP_STEPS > 1
+    e = __builtin_fmaf(-x, y, 1.0f);
+    y = __builtin_fmaf(y, e, y);
+#endif
+    return y;
+}
+PT_FN bool wave_any(bool p) { return __ballot(p) != 0ull; }
+PT_FN float sqrt_rn(float x) {
+    if (__builtin_expect(wave_any(__float_as_uint(x) - 0x0F800000u >= 0x70000000u), 0)) return sqrtf(x);
+    return sqrt_fast_body(x);
+}
+PT_FN float rcp_rn(float x) {
+    if (__builtin_expect(wave_any(__float_as_uint(x) - 0x0D800000u >= 0x64000000u), 0)) return 1.0f / x;
+    return rcp_fast_body(x);
+}
+PT_FN float rcp_sqrt_rn(float x) {  // 2^-96 <= x < 2^100
+    if (__builtin_expect(wave_any(__float_as_uint(x) - 0x0F800000u >= 0x62000000u), 0)) return 1.0f / sqrtf(x);
+    return rcp_fast_body(sqrt_fast_body(x));
+}
+#else
+inline float sqrt_rn(float x) { return sqrtf(x); }
+inline float rcp_rn(float x) { return 1.0f / x; }
+inline float rcp_sqrt_rn(float x) { return 1.0f / sqrtf(x); }
+#endif
 PT_FN V3 normalize3(V3 v) {
-    float inv = 1.0f / sqrtf(dot3(v, v));
+    float inv = rcp_sqrt_rn(dot3(v, v));
     return v * inv;
 }
 PT_FN V3 reflect3(V3 d, V3 n) {
@@ -330,7 +375,7 @@ PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o,
     float c = dot3(oc, oc) - (s.w * s.w);
     float disc = half_b * half_b - c;
     if (!(disc < 0.0f)) {
-        float sq = sqrtf(disc);
+        float sq = sqrt_rn(disc);
         float t = -half_b - sq;
         bool back = false;
         if (t < 0.0f) {
@@ -397,7 +442,7 @@ PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o,
 PT_FN V3 refract3(V3 i, V3 n, float eta) {
     float cos_theta = fminf(dot3(-i, n), 1.0f);
     V3 perp = eta * (i + cos_theta * n);
-    V3 par = -sqrtf(fabsf(1.0f - dot3(perp, perp))) * n;
+    V3 par = -sqrt_rn(fabsf(1.0f - dot3(perp, perp))) * n;
     return perp + par;
 }
 PT_FN float reflectance(float cosine, float ref_idx) {
@@ -507,9 +552,9 @@ PT_FN bool scatter_glass(const Mem& mem, const SceneLayout& L, const Hit& hit, u
     hit_frame(mem, L, hit, ps, pos, norm);
     const float dist = 0.001f;
     float mir = mem.template load<float>(L.off_glass + (mbits >> 3) * 4u);
-    float ir = hit.back ? mir : 1.0f / mir;
+    float ir = hit.back ? mir : rcp_rn(mir);
     float cos_theta = fminf(dot3(-ps.d, norm), 1.0f);
-    float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
     bool cannot_refract = ir * sin_theta > 1.0f;
     bool do_reflect = cannot_refract;
     if (glass_always_draws || !cannot_refract) {
