@@ -209,18 +209,15 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
         const uint32_t n = P.L.n_nodes;  // the node section starts the blob
         for (uint32_t i = threadIdx.x; i < n; i += BLK) {
             const w4 q0 = src[i * 4u], q1 = src[i * 4u + 1u], q2 = src[i * 4u + 2u], q3 = src[i * 4u + 3u];
-            const uint32_t lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
-            const uint32_t lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
-            const uint32_t a = lds0 + i * LDS_NODE_BYTES;
-#pragma unroll
-            for (uint32_t k = 0; k < 3; k++) {
-                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k) = w2{lo0[k], lo1[k]};
-                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 8u) = w2{hi0[k], hi1[k]};
-                *reinterpret_cast<PT_LDS(w2)*>(a + 24u * k + 16u) = w2{lo0[k], lo1[k]};
-            }
+            const uint32_t q[12] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w};
+            // links to interior nodes become the LDS addresses of their records
             const uint32_t l0 = (int32_t)q3.x >= 0 ? lds0 + q3.x * LDS_NODE_BYTES : q3.x;
             const uint32_t l1 = (int32_t)q3.y >= 0 ? lds0 + q3.y * LDS_NODE_BYTES : q3.y;
-            *reinterpret_cast<PT_LDS(w2)*>(a + 72u) = w2{l0, l1};
+            uint32_t rec[20];
+            node_to_ordered(q, l0, l1, rec);
+            const uint32_t a = lds0 + i * LDS_NODE_BYTES;
+#pragma unroll
+            for (uint32_t k = 0; k < 10; k++) *reinterpret_cast<PT_LDS(w2)*>(a + 8u * k) = w2{rec[2 * k], rec[2 * k + 1]};
         }
         const uint32_t rest = (P.scene_lds_bytes - n * LDS_NODE_BYTES) / 16u;
         for (uint32_t i = threadIdx.x; i < rest; i += BLK)

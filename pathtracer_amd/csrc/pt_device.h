@@ -13,6 +13,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include "pt_types.h"
 
@@ -211,6 +212,29 @@ struct PtrMem {
         q0 = load<f4>(off), q1 = load<f4>(off + 16), q2 = load<f4>(off + 32), ch = load<u2>(off + 48);
     }
     PT_FN void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
+};
+
+// Direction-ordered form of one Node64 (see LDS_NODE_BYTES): q = the 16 words of the node, out = 20
+// words; link0 / link1 are what the record stores as child links.
+PT_FN void node_to_ordered(const uint32_t* q, uint32_t link0, uint32_t link1, uint32_t* out) {
+    // Node64: c0.lo.xyz = q[0..2], c0.hi.xyz = q[3..5], c1.lo.xyz = q[6..8], c1.hi.xyz = q[9..11]
+    for (int k = 0; k < 3; k++) {
+        out[6 * k + 0] = q[k], out[6 * k + 1] = q[6 + k];      // lo0, lo1
+        out[6 * k + 2] = q[3 + k], out[6 * k + 3] = q[9 + k];  // hi0, hi1
+        out[6 * k + 4] = q[k], out[6 * k + 5] = q[6 + k];      // lo0, lo1 again
+    }
+    out[18] = link0, out[19] = link1;
+}
+// Host view of a blob whose nodes were converted to ordered records (links = byte offsets of the
+// records): what the kernels keep in LDS, for the CPU harness.
+struct PtrOrderedMem : PtrMem {
+    static constexpr bool ORDERED_NODES = true;
+    const char* nodes;
+    PT_FN void node_ordered(uint32_t a, const uint32_t* sgn, f4& ax, f4& ay, f4& az, u2& ch) const {
+        const char* p = nodes + a;
+        memcpy(&ax, p + sgn[0], 16), memcpy(&ay, p + 24 + sgn[1], 16), memcpy(&az, p + 48 + sgn[2], 16);
+        memcpy(&ch, p + 72, 8);
+    }
 };
 
 struct Hit {

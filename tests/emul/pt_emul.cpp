@@ -2,6 +2,7 @@
 // library's host-side scene packing on the CPU, one path after another, so that tree building,
 // traversal and scatter logic can be compared with the oracle where no GPU exists.  It is built by
 // tests/conftest.py into tests/emul/ and is not part of libmi355pt.so.
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -45,6 +46,25 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) return -1;
     if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes, bvh_info[3] = L.node_half;
     PtrMem mem{blob.data()};
+    // A float-node scene that the device would stage in LDS is walked there through direction-ordered
+    // records; the harness converts the same way and walks the same code.
+    const bool ordered = !L.node_half && lds_scene_bytes(L) + (size_t)std::max(1u, L.max_depth) * 256u * 4u <= LDS_SCENE_LIMIT;
+    std::vector<char> ordered_nodes;
+    PtrOrderedMem omem;
+    omem.base = blob.data();
+    if (ordered) {
+        ordered_nodes.resize((size_t)L.n_nodes * LDS_NODE_BYTES);
+        for (uint32_t i = 0; i < L.n_nodes; i++) {
+            uint32_t q[16], rec[20];
+            memcpy(q, blob.data() + L.off_nodes + (size_t)i * 64u, 64);
+            const uint32_t l0 = (int32_t)q[12] >= 0 ? q[12] * LDS_NODE_BYTES : q[12];
+            const uint32_t l1 = (int32_t)q[13] >= 0 ? q[13] * LDS_NODE_BYTES : q[13];
+            node_to_ordered(q, l0, l1, rec);
+            memcpy(ordered_nodes.data() + (size_t)i * LDS_NODE_BYTES, rec, LDS_NODE_BYTES);
+        }
+        omem.nodes = ordered_nodes.data();
+    }
+    if (bvh_info && ordered) bvh_info[3] = 2;
     Camera64 cam64v;
     memcpy(&cam64v, cam64, 64);
     CameraRegs cam = load_camera(cam64v);
@@ -69,7 +89,8 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                         Hit hit;
                         HostStack st;
                         cnt = Counters{0, 0, 0};
-                        if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
+                        if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
+                        else if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
                         else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;
                         V3 radiance;
