@@ -170,9 +170,38 @@ __global__ void lbvh_refit(const Sphere32* spheres, const uint32_t* order, int n
     }
 }
 
+// Renumbering so that the head of the node array is the top of the tree (what the path kernels keep in
+// LDS for scenes in global memory): the `top` nodes with the largest boxes come first, largest first;
+// all others keep their relative order, which is spatially coherent (node i sits next to leaf i).
+// Sort key of node i: its box's surface area, inverted so that an ascending sort puts the largest first
+// (areas are non-negative, so their bit patterns order like the values; the sort is stable and the root
+// is node 0, so the root stays first).
+__global__ void lbvh_area_keys(const float* node_box, int n_nodes, uint32_t* keys, uint32_t* vals) {
+    const int i = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (i >= n_nodes) return;
+    const float* b = node_box + (size_t)i * 6;
+    const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+    keys[i] = ~__float_as_uint(dx * dy + dy * dz + dz * dx);
+    vals[i] = (uint32_t)i;
+}
+// by_area[r] = node with the r-th largest box.  below[i] = 1 for nodes outside the top.
+__global__ void lbvh_mark_top(const uint32_t* by_area, int n_nodes, int top, uint32_t* below) {
+    const int r = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (r >= n_nodes) return;
+    below[by_area[r]] = r < top ? 0u : 1u;
+}
+// new_id of a top node = its rank by area; of any other node = top + number of non-top nodes before it.
+__global__ void lbvh_new_ids(const uint32_t* by_area, const uint32_t* below, const uint32_t* below_before, int n_nodes,
+                             int top, uint32_t* new_id) {
+    const int r = (int)(blockIdx.x * BLK + threadIdx.x);
+    if (r >= n_nodes) return;
+    if (r < top) new_id[by_area[r]] = (uint32_t)r;
+    if (below[r]) new_id[r] = (uint32_t)top + below_before[r];
+}
+
 // The 64-byte records the path kernels walk: both child boxes and both links per internal node.
 __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n, const int32_t* child0,
-                          const int32_t* child1, const float* node_box, Node64* out) {
+                          const int32_t* child1, const float* node_box, const uint32_t* new_id, Node64* out) {
     const int i = (int)(blockIdx.x * BLK + threadIdx.x);
     if (i >= n - 1) return;
     Box b[2];
@@ -188,7 +217,7 @@ __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n,
                 b[side].lo[k] = node_box[(size_t)c[side] * 6 + k];
                 b[side].hi[k] = node_box[(size_t)c[side] * 6 + 3 + k];
             }
-            link[side] = c[side];
+            link[side] = (int32_t)new_id[c[side]];
         }
     }
     Node64 nd;
@@ -197,7 +226,7 @@ __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n,
     nd.q2 = f4{b[1].lo[2], b[1].hi[0], b[1].hi[1], b[1].hi[2]};
     nd.child0 = link[0], nd.child1 = link[1];
     nd.pad[0] = nd.pad[1] = 0u;
-    out[i] = nd;
+    out[new_id[i]] = nd;
 }
 
 // Spheres and their material words in leaf (= sorted) order; the tie rank is the sphere's index.
@@ -253,8 +282,18 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         err = "lbvh: out of device memory";
         return false;
     }
-    size_t sort_bytes = 0;
+    uint32_t *area_keys, *area_keys_sorted, *area_vals, *by_area, *below, *below_before, *new_id;
+    if (!tmp.get(&area_keys, n) || !tmp.get(&area_keys_sorted, n) || !tmp.get(&area_vals, n) || !tmp.get(&by_area, n) ||
+        !tmp.get(&below, n) || !tmp.get(&below_before, n) || !tmp.get(&new_id, n)) {
+        err = "lbvh: out of device memory";
+        return false;
+    }
+    const uint32_t n_nodes = n - 1u, top = std::min(n_nodes, 4096u);
+    size_t sort_bytes = 0, sort32_bytes = 0, scan_bytes = 0;
     PT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
+    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_nodes, 0, 32, st));
+    PT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, below, below_before, 0u, n_nodes, rocprim::plus<uint32_t>(), st));
+    sort_bytes = std::max(sort_bytes, std::max(sort32_bytes, scan_bytes));
     char* sort_tmp;
     if (!tmp.get(&sort_tmp, sort_bytes)) {
         err = "lbvh: out of device memory";
@@ -285,7 +324,14 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
                        parent_of_leaf);
     hipLaunchKernelGGL(lbvh_refit, grid, block, 0, st, spheres, order, (int)n, child0, child1, parent_of_node,
                        parent_of_leaf, arrived, node_box, max_depth);
-    hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box,
+    hipLaunchKernelGGL(lbvh_area_keys, grid, block, 0, st, node_box, (int)n_nodes, area_keys, area_vals);
+    PT_HIP(hipGetLastError());
+    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_nodes, 0, 32, st));
+    hipLaunchKernelGGL(lbvh_mark_top, grid, block, 0, st, by_area, (int)n_nodes, (int)top, below);
+    PT_HIP(hipGetLastError());
+    PT_HIP(rocprim::exclusive_scan(sort_tmp, sort_bytes, below, below_before, 0u, n_nodes, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(lbvh_new_ids, grid, block, 0, st, by_area, below, below_before, (int)n_nodes, (int)top, new_id);
+    hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box, new_id,
                        reinterpret_cast<Node64*>(d->scene + L.off_nodes));
     hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
                        reinterpret_cast<u2*>(d->scene + L.off_info));

@@ -1,6 +1,7 @@
 """A/B timing of kernel variants in one process, interleaved rounds (development aid; run via gpurun).
 usage: python tools/ab.py [name=ENV1=val;ENV2=val ...]
-env: AB_SCENE=file.ron | AB_SPHERES=n (synthetic plane), AB_W, AB_H, AB_F (frames per launch), AB_ROUNDS"""
+env: AB_SCENE=file.ron | AB_SPHERES=n (synthetic plane), AB_W, AB_H, AB_F (frames per launch), AB_ROUNDS;
+a variant may set AB_BVH=sah|reference|lbvh (tree builder)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -14,6 +15,9 @@ for a in sys.argv[1:]:
 if not variants:
     variants = {"lockstep": {"MI355PT_KERNEL": "lockstep"}, "sched": {}}
 KEYS = sorted({k for v in variants.values() for k in v})
+
+def bvh_mode():
+    return {"sah": pa.BVH_SAH, "reference": pa.BVH_REFERENCE, "lbvh": pa.BVH_LBVH}[os.environ.get("AB_BVH", "sah")]
 
 def setenv(v):
     for k in KEYS:
@@ -38,7 +42,7 @@ W, H, seeds = 160, 90, [11, 22, 33]
 ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
 for name, v in variants.items():
     setenv(v)
-    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=bvh_mode()) as r:
         r.render(seeds=seeds)
         bad = int((r.read_accum().view(np.uint32) != ref.view(np.uint32)).any(axis=2).sum())
         print(f"parity {name}: {'bit-identical' if bad == 0 else f'{bad} of {W*H} pixels differ'} rays {r.stats()['rays']} vs {st['rays']}", flush=True)
@@ -48,7 +52,7 @@ W, H, F = int(os.environ.get("AB_W", 1920)), int(os.environ.get("AB_H", 1080)), 
 rs = {}
 for name, v in variants.items():   # one renderer per variant: scene-build switches apply at creation
     setenv(v)
-    rs[name] = pa.Renderer(sc, pa.Settings(1, 50), W, H)
+    rs[name] = pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=bvh_mode())
 res = {n: [] for n in variants}
 for rnd in range(int(os.environ.get("AB_ROUNDS", 5))):
     for name, v in variants.items():
