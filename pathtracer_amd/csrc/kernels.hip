@@ -496,7 +496,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         // ---- finished walks: fetch the material word and sort the lane into its scatter class
         if (w.cur == WALK_FINISHED) {
             Hit hit;
-            hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+            walk_result(w, hit);
             mbits = hit_material(mem, P.L, hit);
             const uint32_t cls = scatter_class(mbits, hit.back);
             w.cur = cls == SC_OPAQUE ? LANE_OPAQUE : (cls == SC_GLASS ? LANE_GLASS : LANE_TERMINAL);
@@ -512,7 +512,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
             ran = true;
             if (w.cur == LANE_OPAQUE) {
                 Hit hit;
-                hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+                walk_result(w, hit);
                 V3 radiance;
                 if (scatter_opaque(mem, P.L, hit, mbits, ps, P.depth, radiance)) {
                     finish_sample(radiance);
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
             ran = true;
             if (w.cur == LANE_GLASS) {
                 Hit hit;
-                hit.t = w.best_t, hit.idx = w.best_idx, hit.back = w.best_back;
+                walk_result(w, hit);
                 V3 radiance;
                 if (scatter_glass(mem, P.L, hit, mbits, ps, P.depth, P.glass_always_draws != 0, radiance)) {
                     finish_sample(radiance);

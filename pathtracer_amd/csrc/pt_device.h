@@ -271,8 +271,11 @@ PT_FN bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz
 struct Walk {
     V3 inv, ood;       // reciprocal direction and origin * inv, for the slab tests only
     float best_t;
-    int32_t best_idx;  // leaf-order sphere index, -1 = none yet
-    bool best_back;
+    // Leaf-order index of the closest sphere so far, with WALK_BACK_BIT set when the ray leaves it
+    // from inside; -1 = none yet.  One vector register on purpose: a separate bool would live in a
+    // scalar register pair as a lane mask and cost three scalar instructions per nested branch of
+    // the sphere test, and the scalar unit is shared by the four SIMDs of a compute unit.
+    int32_t best_code;
     int32_t cur;       // >= 0 interior node to visit; leaf link (see walk_is_leaf); or WALK_FINISHED
     int32_t sp;        // entries on the traversal stack
     uint32_t sgn[3];   // 8 where the direction component is negative, else 0 (direction-ordered nodes)
@@ -280,6 +283,13 @@ struct Walk {
 // Leaf links are ~(first | (count-1) << 28) and lie in [-2^30, -1]; values below are free for
 // the walk's end marker and for the kernels' own lane states.
 constexpr int32_t WALK_FINISHED = INT32_MIN;
+constexpr uint32_t WALK_BACK_BIT = 1u << 30;  // sphere indices stay below 2^28 (LEAF_FIRST_MASK)
+PT_FN uint32_t walk_best_idx(const Walk& w) { return (uint32_t)w.best_code & (WALK_BACK_BIT - 1u); }
+PT_FN void walk_result(const Walk& w, Hit& hit) {  // t is set by the caller's own copy where it keeps one
+    hit.t = w.best_t;
+    hit.idx = w.best_code < 0 ? -1 : (int32_t)walk_best_idx(w);
+    hit.back = ((uint32_t)w.best_code & WALK_BACK_BIT) != 0u && w.best_code >= 0;
+}
 PT_FN bool walk_is_node(int32_t cur) { return cur >= 0; }
 PT_FN bool walk_is_leaf(int32_t cur) { return (uint32_t)cur >= 0xC0000000u; }
 
@@ -297,8 +307,7 @@ PT_FN void walk_begin(Walk& w, const SceneLayout& L, V3 o, V3 d, int32_t root = 
     if (HALF) o = o - mk(L.box_org[0], L.box_org[1], L.box_org[2]);  // half boxes are relative to box_org
     w.ood = mk(o.x * w.inv.x, o.y * w.inv.y, o.z * w.inv.z);
     w.best_t = INFINITY;
-    w.best_idx = -1;
-    w.best_back = false;
+    w.best_code = -1;
     w.cur = root;  // a scene has >= 2 spheres, so node 0 is interior; `root` is its link in the view's terms
     w.sp = 0;
 }
@@ -408,16 +417,15 @@ PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o,
         }
         if (!(t < 0.0f)) {
             bool take = t < w.best_t;
-            if (t == w.best_t && w.best_idx >= 0) {
+            if (t == w.best_t && w.best_code >= 0) {
                 uint32_t rank = mem.template load<u2>(L.off_info + si * 8u).y;
-                uint32_t best_rank = mem.template load<u2>(L.off_info + (uint32_t)w.best_idx * 8u).y;
+                uint32_t best_rank = mem.template load<u2>(L.off_info + walk_best_idx(w) * 8u).y;
                 take = rank > best_rank;
             }
             if (take) {
                 if (COUNT) cnt.accepted++;
                 w.best_t = t;
-                w.best_idx = (int32_t)si;
-                w.best_back = back;
+                w.best_code = (int32_t)(si | (back ? WALK_BACK_BIT : 0u));
             }
         }
     }
@@ -457,9 +465,7 @@ PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o,
         if (w.cur == WALK_FINISHED) break;
         walk_leaf<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
     }
-    hit.t = w.best_t;
-    hit.idx = w.best_idx;
-    hit.back = w.best_back;
+    walk_result(w, hit);
 }
 
 // ---- materials: compute.wgsl:197-207, 269-368 ---------------------------------------------------

@@ -349,7 +349,8 @@ int main(int argc, char** argv) {
                         else walk_leaf_one<PtrMem, HostStack, false>(mem, L, st, w, ps.o, ps.d, cnt), sg.steps += 'L';
                     }
                     rays++;
-                    Hit hit{w.best_t, w.best_idx, w.best_back};
+                    Hit hit;
+                    walk_result(w, hit);
                     const uint32_t mbits = hit_material(mem, L, hit);
                     const uint32_t cls = scatter_class(mbits, hit.back);
                     sg.cls = cls == SC_OPAQUE ? 'O' : (cls == SC_GLASS ? 'G' : 'T');
