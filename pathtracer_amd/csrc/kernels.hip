@@ -381,11 +381,15 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
 // reaches its threshold every non-empty state runs once, which guarantees progress.  Scheduling only
 // reorders work between independent paths; every path performs exactly the arithmetic of the
 // lockstep kernel.
-constexpr int32_t LANE_IDLE = INT32_MIN + 1;      // needs a path or the next sample's camera ray
-constexpr int32_t LANE_EXIT = INT32_MIN + 2;      // queue empty, nothing left to do
+// (All per-lane state lives in vector registers: a bool per lane would be a lane mask in a scalar register
+// pair, updated with three scalar instructions per nested branch, and the scalar unit is the scarcer one.)
+constexpr int32_t LANE_IDLE = INT32_MIN + 1;      // needs a path
+constexpr int32_t LANE_NEXT = INT32_MIN + 2;      // has a path, needs the camera ray of its next sample
 constexpr int32_t LANE_TERMINAL = INT32_MIN + 3;  // path ends at this hit / miss; radiance still to add
-constexpr int32_t LANE_OPAQUE = INT32_MIN + 4;
-constexpr int32_t LANE_GLASS = INT32_MIN + 5;
+constexpr int32_t LANE_EXIT = INT32_MIN + 4;      // queue empty, nothing left to do
+constexpr int32_t LANE_OPAQUE = INT32_MIN + 5;
+constexpr int32_t LANE_GLASS = INT32_MIN + 6;
+__device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32_t)(cur - LANE_IDLE) <= 2u; }
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
 template <int SCENE, bool COUNT, int BLK>
@@ -414,7 +418,6 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     const float fw = (float)P.width, fh = (float)P.height;
     const uint32_t lane = threadIdx.x & 63u;
 
-    bool have_path = false;  // idle with a path: only the next sample's camera ray is needed
     PathState ps;
     ps.o = ps.d = ps.colour = mk(0.0f, 0.0f, 0.0f);
     ps.rng = 1u;
@@ -440,7 +443,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     auto finish_sample = [&](V3 radiance) {
         final_colour = final_colour + radiance;
         sample_i++;
-        w.cur = LANE_IDLE;
+        w.cur = LANE_NEXT;
         if (sample_i >= P.samples) {
             f4 o4;
             o4.x = final_colour.x, o4.y = final_colour.y, o4.z = final_colour.z;
@@ -452,7 +455,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
             }
             o4.w = (float)rays;  // summed per pixel by the accumulation kernel: ray total and tile costs
             P.frame_out[out_index] = o4;
-            have_path = false;
+            w.cur = LANE_IDLE;
         }
     };
     auto wants = [&](bool mine, int ph) -> bool {
@@ -540,10 +543,10 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         // ---- restart: close the paths that end at this hit / miss, hand consecutive path ids from the
         // wave's chunk to lanes without a path, start the next sample.  One step on purpose: every
         // path needs both halves exactly once, and a separate state would only thin out the others.
-        if (wants(w.cur == LANE_IDLE || w.cur == LANE_TERMINAL, PH_IDLE)) {
+        if (wants(lane_wants_restart(w.cur), PH_IDLE)) {
             ran = true;
             if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
-            unsigned long long m = __ballot(w.cur == LANE_IDLE && !have_path);
+            unsigned long long m = __ballot(w.cur == LANE_IDLE);
             while (m) {
                 if (next == end) {
                     if (exhausted) break;
@@ -568,7 +571,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 }
                 const uint32_t avail = end - next;
                 const uint32_t rank = lane_rank(m);
-                if (w.cur == LANE_IDLE && !have_path && rank < avail) {
+                if (w.cur == LANE_IDLE && rank < avail) {
                     const uint32_t pid = next + rank;
                     const uint32_t unit = pid >> 6, slot = pid & 63u;
                     uint32_t frame, tile, tx, ty;
@@ -593,23 +596,20 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                         final_colour = mk(0.0f, 0.0f, 0.0f);
                         sample_i = 0;
                         rays = 0;
-                        have_path = true;
+                        w.cur = LANE_NEXT;
                     }
                 }
                 next += min((uint32_t)__popcll(m), avail);
-                m = __ballot(w.cur == LANE_IDLE && !have_path);
+                m = __ballot(w.cur == LANE_IDLE);
             }
-            if (w.cur == LANE_IDLE) {
-                if (have_path) {
-                    ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
-                    ps.o = cam.pos;
-                    ps.colour = mk(1.0f, 1.0f, 1.0f);
-                    ps.bounce = 0;
-                    walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
-                    rays++;
-                } else {
-                    w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
-                }
+            if (w.cur == LANE_IDLE) w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
+            if (w.cur == LANE_NEXT) {
+                ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
+                ps.o = cam.pos;
+                ps.colour = mk(1.0f, 1.0f, 1.0f);
+                ps.bounce = 0;
+                walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
+                rays++;
             }
         }
         if (!ran) {
