@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     };
     auto wants = [&](bool mine, int ph) -> bool {
         const uint32_t n = (uint32_t)__popcll(__ballot(mine));
-        const bool go = n >= P.thr[ph] || (force && n);
+        const bool go = n >= (force ? 1u : P.thr[ph]);  // thresholds are >= 1
         if (COUNT && go) ph_exec[ph]++, ph_lanes[ph] += n;
         return go;
     };
