@@ -149,7 +149,7 @@ def main():
             "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, {F} frames/step x {args.steps} steps "
-                                   f"per GPU, 1 spp/frame, depth 50 (BASELINE configs[1])",
+                                   f"per GPU, 1 spp/frame, depth 50",
                        "frames_per_gpu": F * args.steps, "paths_per_step_per_gpu": W * H * F,
                        "parallelism": f"frame-partitioned x{world}, one {'RCCL' if backend == 'nccl' else backend} sum-reduce"
                                       if world > 1 else "1 GPU",

@@ -376,7 +376,7 @@ def test_validation_errors(pa):
 
 
 def test_full_size_properties_scene1_1080p(pa, orc):
-    # BASELINE configuration size; the oracle is too slow here, so check what does not depend on it
+    # the headline configuration's size; the oracle is too slow here, so check what does not depend on it
     sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
     W, H = 1920, 1080
     seeds = [pa.frame_seed(0x00C0FFEE, f) for f in range(32)]

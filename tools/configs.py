@@ -1,4 +1,4 @@
-"""Runs the BASELINE configurations on one GPU and prints one JSON line per configuration
+"""Runs the benchmark configurations on one GPU and prints one JSON line per configuration
 (development / documentation aid; run via gpurun).   usage: python tools/configs.py [c1 c2 c3a c3b c4 ...]"""
 import json, os, sys, time
 import numpy as np
