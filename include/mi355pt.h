@@ -42,7 +42,7 @@ enum {
 enum {
     MI355PT_BVH_SAH = 0,       /* library builds a binned-SAH tree (default) */
     MI355PT_BVH_REFERENCE = 1, /* library builds the reference's own tree (bvh.rs:51-140, no child swap) */
-    MI355PT_BVH_LBVH = 2       /* tree built on the GPU (Morton order, single-sphere leaves): fastest set_scene,
+    MI355PT_BVH_LBVH = 2       /* tree built on the GPU (Morton order, leaves of one or two spheres): fastest set_scene,
                                   more node visits per ray; exact ties in t resolve by sphere index */
 };
 

