@@ -280,7 +280,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
                 if (exhausted) break;
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(P.work_counter, chunk);
-                base = __shfl(base, 0);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // lane 0 is active here: the step is entered by the whole wave
                 if (base >= P.total_units) {
                     exhausted = true;
                     break;
@@ -552,7 +552,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                     if (exhausted) break;
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(P.work_counter, chunk);
-                    base = __shfl(base, 0);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // lane 0 is active here: the step is entered by the whole wave
                     if (base >= P.total_units) {
                         exhausted = true;
                         break;
