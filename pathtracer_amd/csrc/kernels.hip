@@ -167,7 +167,7 @@ struct RenderParams {
     int32_t glass_always_draws;
     uint64_t watchdog_ticks;  // 100 MHz ticks after which a wave gives up (scheduling-bug guard)
     uint32_t thr[6];  // pt_render_sched_kernel: lanes that must wait for a step before it runs: node, leaf,
-                      // terminal, opaque, glass, idle
+                      // (unused: terminal lanes are served by the restart step), opaque, glass, restart
     float inv_tiles_x;
     uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
     float inv_share;  // 1 / (2 * waves in the grid), for the chunk size
@@ -1094,7 +1094,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     P.counters = d->counters;
     P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
     // Development switches (not part of the ABI): MI355PT_KERNEL=lockstep selects the simple kernel,
-    // MI355PT_SCHED="node,leaf,terminal,opaque,glass,idle" overrides the step thresholds.
+    // MI355PT_SCHED="node,leaf,-,opaque,glass,restart" overrides the step thresholds (the third is unused).
     const char* kenv = getenv("MI355PT_KERNEL");
     const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
@@ -1105,8 +1105,6 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
             for (int k = 0; k < 6; k++) P.thr[k] = t[k] < 1 ? 1 : (t[k] > 64 ? 64 : t[k]);
-    }
-    {
     }
     {
         const char* cenv = getenv("MI355PT_CHUNK");  // development switch
