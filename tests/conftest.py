@@ -64,6 +64,7 @@ def emul():
     L.emul_pixel_hash.argtypes = [C.c_uint32] * 4
     L.emul_det_sin.restype = C.c_float
     L.emul_det_sin.argtypes = [C.c_float]
+    L.emul_set_brute_force.argtypes = [C.c_int]
 
     def render(sc, cam, W, H, seeds, samples=1, depth=50, ref_topo=0, ref_nodes=None, crop=None, glass=1):
         acc = np.zeros((H, W, 4), np.float32)

@@ -4,6 +4,7 @@
 // tests/conftest.py into tests/emul/ and is not part of libmi355pt.so.
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -21,11 +22,16 @@ struct HostStack {
     int32_t pop(int sp) const { return a[sp]; }
 };
 std::string g_err;
+int g_brute_force = 0;
+bool g_log = true;
 }  // namespace
 
 extern "C" {
 
 const char* emul_error() { return g_err.c_str(); }
+// 1: closest hits are found by testing every sphere (no tree, no boxes); 2: the same with each sphere's own
+// padded box as the only cull, logging every root that box would hide
+void emul_set_brute_force(int mode) { g_brute_force = mode; }
 
 // counters: nodes, tests, accepted, bounce[5], rays, paths
 int emul_render(const void* spheres32, size_t n_spheres, const void* lights, size_t n_lights, const void* lamb,
@@ -89,7 +95,30 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                         Hit hit;
                         HostStack st;
                         cnt = Counters{0, 0, 0};
-                        if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
+                        if (g_brute_force) {  // every sphere, no boxes: what no tree can change
+                            Walk w;
+                            walk_begin<false>(w, L, ps.o, ps.d);
+                            for (uint32_t si = 0; si < L.n_spheres; si++) {
+                                if (g_brute_force == 2) {  // with every sphere's own padded box as the only cull
+                                    const f4 sp = mem.load<f4>(L.off_spheres + si * 16u);
+                                    float tn;
+                                    const bool in = slab((sp.x - sp.w) - 0.01f, (sp.y - sp.w) - 0.01f, (sp.z - sp.w) - 0.01f,
+                                                         (sp.x + sp.w) + 0.01f, (sp.y + sp.w) + 0.01f, (sp.z + sp.w) + 0.01f, w.inv,
+                                                         w.ood, w.best_t, tn);
+                                    if (!in) {
+                                        Walk probe = w;
+                                        probe.best_t = INFINITY, probe.best_code = -1;
+                                        walk_test_sphere<PtrMem, false>(mem, L, probe, ps.o, ps.d, si, cnt);
+                                        if (probe.best_code >= 0 && probe.best_t < w.best_t && g_log)
+                                            fprintf(stderr, "pixel %u,%u frame %u bounce %d: sphere %u (r %g) root t=%.9g culled by its own box; o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) best_t=%.9g\n",
+                                                    x, y, f, ps.bounce, si, sp.w, probe.best_t, ps.o.x, ps.o.y, ps.o.z, ps.d.x, ps.d.y, ps.d.z, w.best_t);
+                                        continue;
+                                    }
+                                }
+                                walk_test_sphere<PtrMem, true>(mem, L, w, ps.o, ps.d, si, cnt);
+                            }
+                            walk_result(w, hit);
+                        } else if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
                         else if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
                         else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;

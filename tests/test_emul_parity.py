@@ -229,3 +229,20 @@ def test_random_scenes(emul, orc, pa, seed):
     for topo in (0, 1):
         acc, cnt, _ = emul.render(sc, cam, W, H, SEEDS[:2], samples=samples, depth=depth, ref_topo=topo)
         assert bits_equal(ref, acc) and cnt["rays"] == st["rays"]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tree_walk_equals_brute_force(emul, pa, orc, seed):
+    # closest hits found by testing every sphere, without any box, give the same image as the tree walk
+    sc = random_scene(pa, 3000 + seed)
+    osc = oracle_scene(orc, sc)
+    W, H = 32, 20
+    cam = osc.camera(W, H)
+    tree, cnt, _ = emul.render(sc, cam, W, H, SEEDS[:2])
+    emul.emul_set_brute_force(1)
+    try:
+        brute, cnt_b, _ = emul.render(sc, cam, W, H, SEEDS[:2])
+    finally:
+        emul.emul_set_brute_force(0)
+    assert bits_equal(tree, brute) and cnt["rays"] == cnt_b["rays"]
+    assert cnt_b["tests"] > cnt["tests"]
