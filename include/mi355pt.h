@@ -41,7 +41,11 @@ enum {
 
 enum {
     MI355PT_BVH_SAH = 0,       /* library builds a binned-SAH tree (default) */
-    MI355PT_BVH_REFERENCE = 1, /* library builds the reference's own tree (bvh.rs:51-140, no child swap) */
+    MI355PT_BVH_REFERENCE = 1, /* library builds the reference's own tree (bvh.rs:51-140, no child swap) and walks
+                                  it the reference's way (compute.wgsl:85-96, 236-268: its box arithmetic, no
+                                  pruning, no box test for a leaf): exactly the spheres the reference tries are
+                                  tried, so results equal the reference's even for the rare rays whose computed
+                                  root lies outside its sphere's box; several times slower than the default */
     MI355PT_BVH_LBVH = 2       /* tree built on the GPU (Morton order, leaves of one or two spheres): fastest set_scene,
                                   more node visits per ray; exact ties in t resolve by sphere index */
 };
@@ -94,7 +98,7 @@ int mi355pt_set_scene(mi355pt_ctx* ctx, const void* spheres32, size_t n_spheres,
                       size_t n_metals, const void* glass4, size_t n_glass);
 /* Optional: use a caller-built tree in the reference's flattened format (the bytes bound at
  * @group(1) @binding(0), compute.wgsl:184-185).  Call after mi355pt_set_scene().  The library keeps
- * the topology and re-encodes the nodes for its kernels. */
+ * the topology, re-encodes the nodes for its kernels and walks them as under MI355PT_BVH_REFERENCE. */
 int mi355pt_set_bvh(mi355pt_ctx* ctx, const void* nodes48, size_t n_nodes);
 
 /* ---- camera: the uniform at @group(0) @binding(1) (compute.wgsl:178-179) ---------------------

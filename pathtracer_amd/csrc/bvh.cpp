@@ -177,7 +177,13 @@ struct RefConverter {
         uint32_t right = left_end;
         size_t me = out->nodes.size();
         out->nodes.push_back(Node64{});
-        set_child_boxes(out->nodes[me], nodes[left].mn, nodes[left].mx, nodes[right].mn, nodes[right].mx);
+        // The reference tests a node's box when it visits the node and tests a leaf's sphere without any
+        // box of its own (compute.wgsl:244-262): a sphere is tried whenever its parent's box was hit.  A
+        // leaf child therefore carries the parent's box here.
+        const Node48& l = nodes[left];
+        const Node48& r = nodes[right];
+        set_child_boxes(out->nodes[me], l.type == 1u ? nd.mn : l.mn, l.type == 1u ? nd.mx : l.mx,
+                        r.type == 1u ? nd.mn : r.mn, r.type == 1u ? nd.mx : r.mx);
         int32_t c0, c1;
         if (!conv(left, left_end, depth + 1, &c0)) return false;
         if (!conv(right, end, depth + 1, &c1)) return false;

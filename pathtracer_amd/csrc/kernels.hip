@@ -193,7 +193,8 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 }
 
 // SCENE: where the scene blob is read from and which node format it holds.
-enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2 };
+// SCENE_REFERENCE: memory as SCENE_GLOBAL, nodes walked the reference's way (SceneLayout::reference_walk).
+enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2, SCENE_REFERENCE = 3 };
 template <int SCENE> struct SceneMem { typedef HybridMem type; };
 template <> struct SceneMem<SCENE_LDS> { typedef LdsOrderedMem type; };
 template <> struct SceneMem<SCENE_LDS_HALF> { typedef LdsMem type; };
@@ -231,7 +232,7 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
 
 template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
-    constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
+    constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
     stage_scene<SCENE, BLK>(P, lds0);
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
         // ---- extend + scatter
         if (alive) {
             Hit hit;
-            closest_hit<Mem, Stack, COUNT, HALF>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
+            closest_hit<Mem, Stack, COUNT, HALF, SCENE == SCENE_REFERENCE>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
             nrays++;
             V3 radiance;
             uint32_t mat;
@@ -394,7 +395,7 @@ enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT
 
 template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams P) {
-    constexpr bool LDS_SCENE = SCENE != SCENE_GLOBAL, HALF = SCENE == SCENE_LDS_HALF;
+    constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
     stage_scene<SCENE, BLK>(P, lds0);
@@ -477,7 +478,10 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         if (wants(walk_is_node(w.cur), PH_NODE)) {
             ran = true;
             for (;;) {
-                if (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT, HALF>(mem, P.L, stack, w, cnt);
+                if (walk_is_node(w.cur)) {
+                    if constexpr (SCENE == SCENE_REFERENCE) walk_node_reference<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
+                    else walk_node<Mem, Stack, COUNT, HALF>(mem, P.L, stack, w, cnt);
+                }
                 const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_node(w.cur)));
                 if (n < (force ? 1u : P.thr[PH_NODE])) break;  // a forced round drains the state
                 if (COUNT) ph_exec[PH_NODE]++, ph_lanes[PH_NODE] += n;
@@ -836,7 +840,7 @@ bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
     d->layout = layout;
     d->have_scene = true;
     d->perm_valid = false;
-    d->scene_in_lds = lds_scene_bytes(layout) + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
+    d->scene_in_lds = !layout.reference_walk && lds_scene_bytes(layout) + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
         d->have_scene = false;
@@ -946,6 +950,9 @@ static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_byt
     if (scene_mode == SCENE_LDS)
         return count ? launch_render<SCENE_LDS, true, BLK>(d, P, lds_bytes, lockstep, err)
                      : launch_render<SCENE_LDS, false, BLK>(d, P, lds_bytes, lockstep, err);
+    if (scene_mode == SCENE_REFERENCE)
+        return count ? launch_render<SCENE_REFERENCE, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_REFERENCE, false, BLK>(d, P, lds_bytes, lockstep, err);
     return count ? launch_render<SCENE_GLOBAL, true, BLK>(d, P, lds_bytes, lockstep, err)
                  : launch_render<SCENE_GLOBAL, false, BLK>(d, P, lds_bytes, lockstep, err);
 }
@@ -1112,7 +1119,8 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         if (cenv && atoi(cenv) > 0) P.chunk_max = (uint32_t)std::min(1024, atoi(cenv));
     }
     const bool in_lds = d->scene_in_lds;
-    const int scene_mode = in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
+    const int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
+                           : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
     const size_t lds_cu = 160u * 1024u;
     uint32_t block, lds_bytes;
     auto env_int = [](const char* name, long dflt) {

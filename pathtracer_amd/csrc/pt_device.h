@@ -398,6 +398,44 @@ PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
     }
 }
 
+// The reference's own box test (compute.wgsl:85-96), operation for operation: IEEE divisions by the
+// direction (zero components give infinities or NaN, which min / max drop), no clipping against the
+// closest hit so far, strict comparison.
+PT_FN bool slab_reference(float lox, float loy, float loz, float hix, float hiy, float hiz, V3 o, V3 d) {
+    const float x0 = (lox - o.x) / d.x, y0 = (loy - o.y) / d.y, z0 = (loz - o.z) / d.z;
+    const float x1 = (hix - o.x) / d.x, y1 = (hiy - o.y) / d.y, z1 = (hiz - o.z) / d.z;
+    const float sx = fminf(x0, x1), sy = fminf(y0, y1), sz = fminf(z0, z1);
+    const float bx = fmaxf(x0, x1), by = fmaxf(y0, y1), bz = fmaxf(z0, z1);
+    const float tmin = fmaxf(0.0f, fmaxf(sx, fmaxf(sy, sz)));
+    const float tmax = fminf(bx, fminf(by, bz));
+    return tmin < tmax;
+}
+// One interior node of a reference-format tree, walked the reference's way (SceneLayout::reference_walk):
+// the spheres that get tested are exactly those the reference's walk tests (compute.wgsl:236-268), so the
+// result equals the reference's even where a computed root lies outside its sphere's box.  Children in
+// stored order; the order of tests does not matter (ties resolve by rank).
+template <class Mem, class Stack, bool COUNT>
+PT_FN void walk_node_reference(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, V3 o, V3 d, Counters& cnt) {
+    const uint32_t off = L.off_nodes + (uint32_t)w.cur * 64u;
+    f4 q0, q1, q2;
+    u2 ch;
+    mem.node64(off, q0, q1, q2, ch);
+    const bool h0 = slab_reference(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, d);
+    const bool h1 = slab_reference(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, d);
+    if (COUNT) cnt.nodes++;
+    if (h0 && h1) {
+        stack.push(w.sp, (int32_t)ch.y);
+        w.sp++;
+        w.cur = (int32_t)ch.x;
+    } else if (h0) {
+        w.cur = (int32_t)ch.x;
+    } else if (h1) {
+        w.cur = (int32_t)ch.y;
+    } else {
+        walk_pop(w, stack);
+    }
+}
+
 // One sphere against the running closest hit (compute.wgsl:116-135 with t_max = closest so far).
 template <class Mem, bool COUNT>
 PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o, V3 d, uint32_t si, Counters& cnt) {
@@ -455,13 +493,16 @@ PT_FN void walk_leaf_one(const Mem& mem, const SceneLayout& L, Stack& stack, Wal
 }
 
 // Whole query, one ray at a time.
-template <class Mem, class Stack, bool COUNT, bool HALF>
+template <class Mem, class Stack, bool COUNT, bool HALF, bool REFERENCE_WALK = false>
 PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o, V3 d, Hit& hit,
                        Counters& cnt) {
     Walk w;
     walk_begin<HALF>(w, L, o, d, mem.root());
     for (;;) {
-        while (walk_is_node(w.cur)) walk_node<Mem, Stack, COUNT, HALF>(mem, L, stack, w, cnt);
+        while (walk_is_node(w.cur)) {
+            if constexpr (REFERENCE_WALK) walk_node_reference<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
+            else walk_node<Mem, Stack, COUNT, HALF>(mem, L, stack, w, cnt);
+        }
         if (w.cur == WALK_FINISHED) break;
         walk_leaf<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
     }

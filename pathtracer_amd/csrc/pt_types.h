@@ -86,6 +86,9 @@ constexpr int MAX_LEAF_SPHERES = 4;
 struct SceneLayout {
     uint32_t off_nodes, n_nodes;      // Node64[] or, with node_half, Node32[]
     uint32_t node_half;               // 1: nodes are Node32
+    uint32_t reference_walk;          // 1: the tree is the reference's (or a caller's) and is walked the reference's
+                                      // way: its box arithmetic, no pruning against the closest hit, no box of its
+                                      // own for a leaf (a leaf child carries its parent's box)
     float box_org[3];                 // origin the Node32 planes are relative to
     uint32_t off_spheres, n_spheres;  // f4[]  (x, y, z, rad) in leaf order
     uint32_t off_info;                // u2[]  (min(mat_type,4) | mat_index << 3, tie rank) in leaf order
@@ -107,7 +110,7 @@ constexpr uint32_t LDS_SCENE_LIMIT = 64u * 1024u;
 constexpr uint32_t LDS_NODE_BYTES = 80u;
 inline uint32_t lds_scene_bytes(const SceneLayout& L) {
     const uint32_t blob = (L.total_bytes + 15u) & ~15u;
-    return L.node_half ? blob : blob + L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+    return (L.node_half || L.reference_walk) ? blob : blob + L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
 }
 
 }  // namespace pt

@@ -180,7 +180,8 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     const bool force_half = nenv && strcmp(nenv, "half") == 0, force_float = nenv && strcmp(nenv, "float") == 0;
     const bool lds_with_float = bvh.nodes.size() * LDS_NODE_BYTES + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
     const bool lds_with_half = bvh.nodes.size() * sizeof(Node32) + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
-    if (lds_with_half && !force_float && (!lds_with_float || force_half)) {
+    const bool reference_walk = caller_tree || reference_topology;
+    if (!reference_walk && lds_with_half && !force_float && (!lds_with_float || force_half)) {
         std::vector<float> axis(n);
         for (int k = 0; k < 3; k++) {  // origin: median sphere centre, where the detail is
             for (uint32_t i = 0; i < n; i++) axis[i] = a.spheres[i].pos[k];
@@ -193,7 +194,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     }
     // A tree that stays in global memory is renumbered so that any prefix of the node array is the
     // most frequently visited top of the tree; the kernels keep such a prefix in LDS.
-    if (!lds_with_float && !L.node_half) order_top_first(bvh, 4096);
+    if ((!lds_with_float || reference_walk) && !L.node_half) order_top_first(bvh, 4096);
     {
         const SceneLayout sized = make_layout(a, (uint32_t)bvh.nodes.size(), L.node_half != 0);
         if (sized.total_bytes == 0) {
@@ -205,6 +206,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
         L.box_org[0] = org[0], L.box_org[1] = org[1], L.box_org[2] = org[2];
     }
     L.max_depth = bvh.max_depth;
+    L.reference_walk = reference_walk ? 1u : 0u;
     const size_t off = L.total_bytes;
     blob.assign(off, 0);
     if (L.node_half) memcpy(blob.data() + L.off_nodes, half_nodes.data(), half_nodes.size() * sizeof(Node32));

@@ -54,7 +54,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     PtrMem mem{blob.data()};
     // A float-node scene that the device would stage in LDS is walked there through direction-ordered
     // records; the harness converts the same way and walks the same code.
-    const bool ordered = !L.node_half && lds_scene_bytes(L) + (size_t)std::max(1u, L.max_depth) * 256u * 4u <= LDS_SCENE_LIMIT;
+    const bool ordered = !L.node_half && !L.reference_walk && lds_scene_bytes(L) + (size_t)std::max(1u, L.max_depth) * 256u * 4u <= LDS_SCENE_LIMIT;
     std::vector<char> ordered_nodes;
     PtrOrderedMem omem;
     omem.base = blob.data();
@@ -71,6 +71,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
         omem.nodes = ordered_nodes.data();
     }
     if (bvh_info && ordered) bvh_info[3] = 2;
+    if (bvh_info && L.reference_walk) bvh_info[3] = 3;
     Camera64 cam64v;
     memcpy(&cam64v, cam64, 64);
     CameraRegs cam = load_camera(cam64v);
@@ -118,7 +119,8 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                                 walk_test_sphere<PtrMem, true>(mem, L, w, ps.o, ps.d, si, cnt);
                             }
                             walk_result(w, hit);
-                        } else if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
+                        } else if (L.reference_walk) closest_hit<PtrMem, HostStack, true, false, true>(mem, L, st, ps.o, ps.d, hit, cnt);
+                        else if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
                         else if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
                         else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;

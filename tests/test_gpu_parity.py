@@ -46,7 +46,8 @@ def test_bit_identical_to_oracle(pa, orc, name, mode):
     b = gs["bounces"]
     assert [b["light"], b["lambertian"], b["metal"], b["glass"], b["sky"]] == \
            [st[k] for k in ("bounce_light", "bounce_lambertian", "bounce_metal", "bounce_glass", "misses")]
-    assert gs["scene_in_lds"] == 1
+    # the default tree is walked from LDS; the reference's tree is walked the reference's way from global memory
+    assert gs["scene_in_lds"] == (0 if mode == "reference" else 1)
 
 
 def test_committed_goldens(pa):
@@ -255,6 +256,21 @@ def test_random_scenes(pa, orc, block):
                 assert gs["rays"] == st["rays"]
 
 
+@pytest.mark.parametrize("seed", [102866, 104944, 106594, 101557])
+def test_reference_walk_follows_the_reference_where_trees_matter(pa, orc, seed):
+    # scenes found by tools/soak.py in which the spheres a walk tries decide a pixel (see the CPU test of the
+    # same name); the reference-topology mode tries exactly the spheres the reference tries
+    sc = random_scene(pa, seed, duplicates=True)
+    osc = oracle_scene(orc, sc)
+    W, H = 48, 32
+    samples, depth = (1, 50) if seed % 4 else (2, 7)
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, [seed, 7], samples=samples, depth=depth, threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, [seed, 7], samples=samples, depth=depth, bvh_mode=pa.BVH_REFERENCE,
+                         flags=pa.FLAG_COUNT)
+    assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
+    assert gs["tests"] == st["leaf_visits"]
+
+
 def test_large_scene_in_global_memory(pa, orc):
     # ~20k spheres: the scene blob no longer fits the LDS budget, nodes come from L2/HBM
     from pathtracer_amd import synth
@@ -346,6 +362,9 @@ def test_million_spheres_within_the_stated_bound(pa, orc):
     rows = np.unique(np.argwhere(differ)[:, 0])
     assert len(rows) <= 2                         # the horizon
     assert abs(int(gs["rays"]) - int(st["rays"])) <= 8
+    # walking the reference's own tree the reference's way leaves no such pixel
+    acc_r, gs_r = gpu_render(pa, sc, W, H, seeds, bvh_mode=pa.BVH_REFERENCE)
+    assert bits_equal(ref, acc_r) and gs_r["rays"] == st["rays"]
 
 
 def test_validation_errors(pa):

@@ -24,10 +24,11 @@ def render(sc, cam, W, H, seeds, samples, depth, topo=0):
                       vp(seeds.ctypes.data), vp(acc.ctypes.data), C.c_uint32(0), C.c_uint32(W), C.c_uint32(0), C.c_uint32(H), cnt, info)
     assert r == 0, L.emul_error()
     return acc, int(cnt[8])
+DUP = os.environ.get('PROBE_DUP', '0') == '1'
 for seed in [int(a) for a in sys.argv[1:]]:
     W, H = 48, 32
     samples, depth = (1, 50) if seed % 4 else (2, 7)
-    sc = random_scene(pa, seed, duplicates=False)
+    sc = random_scene(pa, seed, duplicates=DUP)
     osc = oracle_scene(orc, sc)
     cam = osc.camera(W, H)
     ref, st = orc.render(osc, cam, W, H, [seed, 7], samples=samples, depth=depth, threads=8)

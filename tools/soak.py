@@ -1,3 +1,5 @@
+"""Development soak: random scenes (tests/conftest.py) x three trees on the GPU against the oracle.
+usage: python tools/soak.py <count> [<first seed>]"""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
@@ -6,7 +8,8 @@ from oracle import orc
 from conftest import random_scene, oracle_scene, bits_equal
 orc.build()
 bad = 0
-for seed in range(20000, 20000 + int(sys.argv[1])):
+start = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
+for seed in range(start, start + int(sys.argv[1])):
     W, H = 48, 32
     samples, depth = (1, 50) if seed % 4 else (2, 7)
     for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE)), (False, (pa.BVH_LBVH,))):
