@@ -212,8 +212,19 @@ def main():
             n_cpu_frames = 64   # a quarter of step 0 (10-20 s of CPU work)
             seeds = step_seeds(0)[:n_cpu_frames]
             t1 = time.perf_counter()
-            _, ost = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=threads)
+            cpu_acc, ost = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=threads)
             cdt = time.perf_counter() - t1
+            # the same frames on the GPU, outside the timed region: full-size parity against the CPU result, with
+            # the default tree and with the reference's tree walked the reference's way
+            parity = {"frames": n_cpu_frames, "size": [W, H]}
+            for name, mode in (("default_tree", pa.BVH_SAH), ("reference_walk", pa.BVH_REFERENCE)):
+                with pa.Renderer(scene, settings, W, H, device=local_rank, bvh_mode=mode) as rp:
+                    rp.render(seeds=seeds)
+                    differ = (rp.read_accum().view(np.uint32) != cpu_acc.view(np.uint32)).any(axis=2)
+                    pst = rp.stats()
+                    parity[name] = {"pixels_differing": int(differ.sum()), "rays_equal": bool(pst["rays"] == ost["rays"]),
+                                    "mrays_per_s": pst["rays"] / pst["render_ms"] / 1e3}
+            out["parity_vs_cpu_baseline"] = parity
             out["cpu_baseline"] = {
                 "value": ost["rays"] / cdt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                 "mpaths_per_s": ost["paths"] / cdt / 1e6,
