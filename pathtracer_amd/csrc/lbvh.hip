@@ -17,6 +17,7 @@
 #include "gpu.h"
 #include "gpu_state.h"
 #include "scene_pack.h"
+#include "pt_device.h"
 
 namespace pt {
 namespace gpu {
@@ -366,7 +367,9 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     if (a.n_lambertians)
         PT_HIP(hipMemcpyAsync(d->scene + L.off_lambertians, a.lambertians, a.n_lambertians * 16, hipMemcpyHostToDevice, st));
     if (a.n_metals) PT_HIP(hipMemcpyAsync(d->scene + L.off_metals, a.metals, a.n_metals * 16, hipMemcpyHostToDevice, st));
-    if (a.n_glass) PT_HIP(hipMemcpyAsync(d->scene + L.off_glass, a.glass, a.n_glass * 4, hipMemcpyHostToDevice, st));
+    std::vector<f4> glass(a.n_glass);  // lives until the synchronisation below
+    for (size_t i = 0; i < a.n_glass; i++) glass[i] = glass_record(a.glass[i]);
+    if (a.n_glass) PT_HIP(hipMemcpyAsync(d->scene + L.off_glass, glass.data(), a.n_glass * 16, hipMemcpyHostToDevice, st));
     int depth = 0;
     PT_HIP(hipMemcpyAsync(&depth, max_depth, sizeof depth, hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));

@@ -516,12 +516,23 @@ PT_FN V3 refract3(V3 i, V3 n, float eta) {
     V3 par = -sqrt_rn(fabsf(1.0f - dot3(perp, perp))) * n;
     return perp + par;
 }
-PT_FN float reflectance(float cosine, float ref_idx) {
+// compute.wgsl:203-207.  The part that depends on the index alone is split off: a glass material is only
+// ever used with eta = ir (leaving) or 1 / ir (entering), so the scene blob carries both and their r0
+// (glass_record), computed on the host with these same IEEE operations.
+PT_FN float reflectance_r0(float ref_idx) {
     float r0 = (1.0f - ref_idx) / (1.0f + ref_idx);
-    r0 = r0 * r0;
+    return r0 * r0;
+}
+PT_FN float reflectance_from_r0(float cosine, float r0) {
     float x = 1.0f - cosine;
     float x2 = x * x;
     return r0 + (1.0f - r0) * (x2 * x2 * x);
+}
+PT_FN float reflectance(float cosine, float ref_idx) { return reflectance_from_r0(cosine, reflectance_r0(ref_idx)); }
+// One glass material in the blob: ir, 1 / ir (compute.wgsl:331-335), r0(ir), r0(1 / ir).
+PT_FN f4 glass_record(float ir) {
+    const float inv = rcp_rn(ir);
+    return f4{ir, inv, reflectance_r0(ir), reflectance_r0(inv)};
 }
 PT_FN V3 sky(float dir_y) {
     float t = (dir_y + 1.0f) / 2.0f;
@@ -622,14 +633,15 @@ PT_FN bool scatter_glass(const Mem& mem, const SceneLayout& L, const Hit& hit, u
     V3 pos, norm;
     hit_frame(mem, L, hit, ps, pos, norm);
     const float dist = 0.001f;
-    float mir = mem.template load<float>(L.off_glass + (mbits >> 3) * 4u);
-    float ir = hit.back ? mir : rcp_rn(mir);
+    const f4 g = mem.template load<f4>(L.off_glass + (mbits >> 3) * 16u);
+    float ir = hit.back ? g.x : g.y;
+    const float r0 = hit.back ? g.z : g.w;
     float cos_theta = fminf(dot3(-ps.d, norm), 1.0f);
     float sin_theta = sqrt_rn(1.0f - cos_theta * cos_theta);
     bool cannot_refract = ir * sin_theta > 1.0f;
     bool do_reflect = cannot_refract;
     if (glass_always_draws || !cannot_refract) {
-        float refl = reflectance(cos_theta, ir);
+        float refl = reflectance_from_r0(cos_theta, r0);
         float rnd = randf(ps.rng);
         do_reflect = cannot_refract || refl > rnd;
     }

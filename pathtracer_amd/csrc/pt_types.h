@@ -95,7 +95,7 @@ struct SceneLayout {
     uint32_t off_lights, n_lights;    // f4[]
     uint32_t off_lambertians, n_lambertians;
     uint32_t off_metals, n_metals;    // f4[]  (albedo, roughness)
-    uint32_t off_glass, n_glass;      // float[]
+    uint32_t off_glass, n_glass;      // f4[]  (ir, 1 / ir, r0(ir), r0(1 / ir)), see glass_record
     uint32_t total_bytes;
     uint32_t max_depth;               // deepest interior-node chain; bounds the traversal stack
 };

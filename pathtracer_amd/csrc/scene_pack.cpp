@@ -129,7 +129,7 @@ SceneLayout make_layout(const SceneArrays& a, uint32_t n_nodes, bool half_nodes)
     L.off_metals = (uint32_t)off, L.n_metals = (uint32_t)a.n_metals;
     off = align16(off + a.n_metals * 16);
     L.off_glass = (uint32_t)off, L.n_glass = (uint32_t)a.n_glass;
-    off = align16(off + a.n_glass * 4);
+    off = align16(off + a.n_glass * 16);
     L.total_bytes = off > 0xfffffff0ull ? 0u : (uint32_t)off;
     L.node_half = half_nodes ? 1u : 0u;
     return L;
@@ -167,7 +167,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     auto align16 = [](size_t x) { return (x + 15u) & ~(size_t)15u; };
     const size_t rest_bytes = align16((size_t)n * sizeof(f4)) + align16((size_t)n * sizeof(u2)) +
                               align16(a.n_lights * 16) + align16(a.n_lambertians * 16) + align16(a.n_metals * 16) +
-                              align16(a.n_glass * 4);
+                              align16(a.n_glass * 16);
     const size_t stack256 = (size_t)std::max(1u, bvh.max_depth) * 256u * 4u;
     // Half-precision boxes for a scene that fits the LDS budget only with them (a walk over LDS
     // sustains several times the record rate of one over the L1/L2 caches), provided rounding the
@@ -222,7 +222,8 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     if (a.n_lights) memcpy(blob.data() + L.off_lights, a.lights, a.n_lights * 16);
     if (a.n_lambertians) memcpy(blob.data() + L.off_lambertians, a.lambertians, a.n_lambertians * 16);
     if (a.n_metals) memcpy(blob.data() + L.off_metals, a.metals, a.n_metals * 16);
-    if (a.n_glass) memcpy(blob.data() + L.off_glass, a.glass, a.n_glass * 4);
+    f4* glass = reinterpret_cast<f4*>(blob.data() + L.off_glass);
+    for (size_t i = 0; i < a.n_glass; i++) glass[i] = glass_record(a.glass[i]);
     return true;
 }
 
