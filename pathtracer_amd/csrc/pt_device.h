@@ -488,7 +488,8 @@ PT_FN void walk_leaf_one(const Mem& mem, const SceneLayout& L, Stack& stack, Wal
     uint32_t si = ref & LEAF_FIRST_MASK;
     uint32_t more = ref >> LEAF_COUNT_SHIFT;
     walk_test_sphere<Mem, COUNT>(mem, L, w, o, d, si, cnt);
-    if (more) w.cur = (int32_t)~((si + 1u) | ((more - 1u) << LEAF_COUNT_SHIFT));
+    // the rest of the leaf: first + 1, count - 1; under the complement that is one addition
+    if (more) w.cur = (int32_t)((uint32_t)w.cur + ((1u << LEAF_COUNT_SHIFT) - 1u));
     else walk_pop(w, stack);
 }
 
