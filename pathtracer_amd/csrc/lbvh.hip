@@ -246,7 +246,7 @@ __global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, uint
     const uint32_t p = blockIdx.x * BLK + threadIdx.x;
     if (p >= n) return;
     const Sphere32 s = spheres[order[p]];
-    out_spheres[p] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad};
+    out_spheres[p] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad * s.rad};
     const uint32_t type = s.mat_type > 3u ? 4u : s.mat_type;
     out_info[p] = u2{type | (s.mat_index << 3), order[p]};
 }

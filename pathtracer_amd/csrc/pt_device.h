@@ -443,7 +443,7 @@ PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o,
     if (COUNT) cnt.tests++;
     V3 oc = o - mk(s.x, s.y, s.z);
     float half_b = dot3(oc, d);
-    float c = dot3(oc, oc) - (s.w * s.w);
+    float c = dot3(oc, oc) - s.w;  // s.w holds rad * rad, the product the shader forms here (compute.wgsl:121)
     float disc = half_b * half_b - c;
     if (!(disc < 0.0f)) {
         float sq = sqrt_rn(disc);

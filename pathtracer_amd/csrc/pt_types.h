@@ -90,7 +90,7 @@ struct SceneLayout {
                                       // way: its box arithmetic, no pruning against the closest hit, no box of its
                                       // own for a leaf (a leaf child carries its parent's box)
     float box_org[3];                 // origin the Node32 planes are relative to
-    uint32_t off_spheres, n_spheres;  // f4[]  (x, y, z, rad) in leaf order
+    uint32_t off_spheres, n_spheres;  // f4[]  (x, y, z, rad * rad) in leaf order
     uint32_t off_info;                // u2[]  (min(mat_type,4) | mat_index << 3, tie rank) in leaf order
     uint32_t off_lights, n_lights;    // f4[]
     uint32_t off_lambertians, n_lambertians;

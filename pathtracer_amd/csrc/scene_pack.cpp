@@ -215,7 +215,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     u2* info = reinterpret_cast<u2*>(blob.data() + L.off_info);
     for (uint32_t i = 0; i < n; i++) {
         const Sphere32& s = a.spheres[bvh.order[i]];
-        sp[i] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad};
+        sp[i] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad * s.rad};
         const uint32_t type = s.mat_type > 3u ? 4u : s.mat_type;
         info[i] = u2{type | (s.mat_index << 3), rank[bvh.order[i]]};
     }

@@ -101,7 +101,8 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                             walk_begin<false>(w, L, ps.o, ps.d);
                             for (uint32_t si = 0; si < L.n_spheres; si++) {
                                 if (g_brute_force == 2) {  // with every sphere's own padded box as the only cull
-                                    const f4 sp = mem.load<f4>(L.off_spheres + si * 16u);
+                                    f4 sp = mem.load<f4>(L.off_spheres + si * 16u);
+                                    sp.w = a.spheres[bvh.order[si]].rad;  // the blob holds rad * rad
                                     float tn;
                                     const bool in = slab((sp.x - sp.w) - 0.01f, (sp.y - sp.w) - 0.01f, (sp.z - sp.w) - 0.01f,
                                                          (sp.x + sp.w) + 0.01f, (sp.y + sp.w) + 0.01f, (sp.z + sp.w) + 0.01f, w.inv,
