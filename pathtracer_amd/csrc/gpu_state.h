@@ -41,6 +41,7 @@ struct Device {
     uint32_t* tile_perm = nullptr; // [tiles]
     uint16_t* rank_chunk = nullptr; // [tiles] chunk size for a chunk that starts in the tile of that rank
     bool perm_valid = false;
+    uint32_t since_measure = 0;  // launches since the tile costs were last measured
     Camera64 perm_cam{};
     int32_t perm_depth = 0, perm_samples = 0;
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()

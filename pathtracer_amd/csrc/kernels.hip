@@ -160,7 +160,11 @@ struct RenderParams {
     const uint16_t* rank_chunk;  // with tile_perm: chunk size by the rank the chunk starts in (cost-aware)
     const uint32_t* seeds;       // one per frame of this launch
     const uint32_t* pixel_hash;  // [n_pix]
-    f4* frame_out;               // [frame][tile rank][slot]: rgb = final_colour / samples, w = rays traced
+    f4* frame_out;               // [frame][tile rank][slot]: rgb = final_colour / samples, w = rays traced;
+                                 // with `compact`: three floats per result, no ray count
+    uint32_t compact;            // 1: 12-byte results; the rays traced are summed per wave into ray_slots instead
+                                 // (launches that measure the tile costs need the count per path: 16-byte results)
+    unsigned long long* ray_slots;
     uint32_t* work_counter;
     unsigned long long* counters;  // nodes, tests, accepted, bounce[5]
     uint32_t scene_lds_bytes;
@@ -230,6 +234,25 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
     __syncthreads();
 }
 
+// One finished pixel-frame.
+__device__ __forceinline__ void store_result(const RenderParams& P, uint32_t index, f4 rgb, uint32_t rays, uint32_t& lane_rays) {
+    if (P.compact) {
+        float* o = reinterpret_cast<float*>(P.frame_out) + (size_t)index * 3u;
+        o[0] = rgb.x, o[1] = rgb.y, o[2] = rgb.z;
+        lane_rays += rays;
+    } else {
+        rgb.w = (float)rays;  // summed per pixel by the accumulation kernel: ray total and tile costs
+        P.frame_out[index] = rgb;
+    }
+}
+// At the end of a path kernel: the rays of a compact launch, one atomic per wave on a striped counter.
+__device__ __forceinline__ void flush_rays(const RenderParams& P, uint32_t lane_rays) {
+    if (!P.compact) return;
+    const unsigned long long total = wave_sum((unsigned long long)lane_rays);
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if ((threadIdx.x & 63u) == 0 && total) atomicAdd(P.ray_slots + (size_t)(wave % RAY_SLOTS) * RAY_SLOT_STRIDE, total);
+}
+
 template <int SCENE, bool COUNT, int BLK>
 __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
@@ -263,7 +286,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     ps.rng = 1u;
     ps.bounce = 0;
     V3 final_colour = mk(0.0f, 0.0f, 0.0f);
-    uint32_t out_index = 0, pxy = 0, nrays = 0;
+    uint32_t out_index = 0, pxy = 0, nrays = 0, lane_rays = 0;
     int32_t sample_i = 0;
     Counters cnt = {0, 0, 0};
     uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
@@ -353,14 +376,15 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
                         o4.y = final_colour.y / fs;
                         o4.z = final_colour.z / fs;
                     }
-                    o4.w = (float)nrays;
-                    P.frame_out[out_index] = o4;
+                    o4.w = 0.0f;
+                    store_result(P, out_index, o4, nrays, lane_rays);
                     alive = false;
                 }
             }
         }
     }
 
+    flush_rays(P, lane_rays);
     if (COUNT) {
         unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
                                    bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
@@ -439,6 +463,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
     uint32_t mbits = 0;  // material word of the hit, valid in the scatter states
     V3 final_colour = mk(0.0f, 0.0f, 0.0f);
     uint32_t out_index = 0, pxy = 0, rays = 0;  // rays of the lane's current path
+    uint32_t lane_rays = 0;                     // rays of all its finished paths (compact launches)
     int32_t sample_i = 0;
     Counters cnt = {0, 0, 0};
     uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
@@ -464,8 +489,8 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 o4.y = final_colour.y / fs;
                 o4.z = final_colour.z / fs;
             }
-            o4.w = (float)rays;  // summed per pixel by the accumulation kernel: ray total and tile costs
-            P.frame_out[out_index] = o4;
+            o4.w = 0.0f;
+            store_result(P, out_index, o4, rays, lane_rays);
             w.cur = LANE_IDLE;
         }
     };
@@ -639,6 +664,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
         }
     }
 
+    flush_rays(P, lane_rays);
     if (COUNT) {
         unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
                                    bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
@@ -666,7 +692,7 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
 // measured 6x slower at 3840x2160.)
 __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
                                   uint32_t tiles, uint32_t n_frames, const uint32_t* tile_perm,
-                                  unsigned long long* ray_total, float* tile_cost) {
+                                  unsigned long long* ray_total, float* tile_cost, uint32_t compact) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t rank = gid >> 6, slot = gid & 63u;
     unsigned long long rays = 0;
@@ -679,13 +705,25 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
             f4 a = accum[i];
             const f4* src = results + (size_t)rank * 64u + slot;
             const size_t frame_stride = (size_t)tiles * 64u;
-            for (uint32_t f = 0; f < n_frames; f++) {
-                f4 s = src[(size_t)f * frame_stride];
-                a.x += s.x;
-                a.y += s.y;
-                a.z += s.z;
-                a.w += 0.0f;
-                rays += (unsigned long long)s.w;
+            if (compact) {  // 12-byte results; the path kernel has counted the rays
+                const float* c = reinterpret_cast<const float*>(results) + ((size_t)rank * 64u + slot) * 3u;
+                const size_t stride = frame_stride * 3u;
+                for (uint32_t f = 0; f < n_frames; f++) {
+                    const float* s = c + (size_t)f * stride;
+                    a.x += s[0];
+                    a.y += s[1];
+                    a.z += s[2];
+                    a.w += 0.0f;
+                }
+            } else {
+                for (uint32_t f = 0; f < n_frames; f++) {
+                    f4 s = src[(size_t)f * frame_stride];
+                    a.x += s.x;
+                    a.y += s.y;
+                    a.z += s.z;
+                    a.w += 0.0f;
+                    rays += (unsigned long long)s.w;
+                }
             }
             accum[i] = a;
         }
@@ -1213,6 +1251,12 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         P.rank_chunk = use_perm ? d->rank_chunk : nullptr;
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = dev_seeds + f0;
+        // The tile costs are measured on the first launch that is long enough to be representative after the
+        // camera or the settings changed, and again every 16th launch; measuring needs the ray count per path
+        // (16-byte results), all other launches write and re-read 12 bytes per path.
+        const bool measure = order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 15u);
+        P.compact = measure ? 0u : 1u;
+        P.ray_slots = d->ray_slots;
         PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
         Device::Timed tr{take_event(d), take_event(d), false};
         PT_HIP(hipEventRecord(tr.begin, d->stream));
@@ -1226,11 +1270,9 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // accumulate in frame order (same stream: launches of one context never overlap)
         Device::Timed ts{take_event(d), take_event(d), true};
         PT_HIP(hipEventRecord(ts.begin, d->stream));
-        // Re-measure the tile costs on launches that are long enough to be representative.
-        const bool measure = order_tiles && nb >= 8u;
         hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
                            d->frame_buf, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
-                           measure ? d->tile_cost : nullptr);
+                           measure ? d->tile_cost : nullptr, P.compact);
         d->timed.push_back(ts);
         PT_HIP(hipGetLastError());
         if (measure) {
@@ -1240,7 +1282,10 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
             d->perm_valid = true;
             d->perm_cam = cam;
             d->perm_depth = cfg.depth, d->perm_samples = cfg.samples;
+            d->since_measure = 0;
             use_perm = true;   // later launches of this call are ordered after the kernel above
+        } else {
+            d->since_measure++;
         }
         PT_HIP(hipEventRecord(ts.end, d->stream));
         d->in_flight = true;
