@@ -540,6 +540,10 @@ __global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams
                 if (COUNT) ph_exec[PH_LEAF]++, ph_lanes[PH_LEAF] += n;
             }
         }
+        // Enough lanes are back at interior nodes (they came out of leaves): walk on before looking at the
+        // scatter states, whose tests cost a dozen scalar instructions per round (scene1, 256 frames:
+        // 20.95 -> 20.70 ms; asking for 8 or 16 lanes more than the node threshold: no gain).
+        if (!force && (uint32_t)__popcll(__ballot(walk_is_node(w.cur))) >= P.thr[PH_NODE]) continue;
         // ---- finished walks: fetch the material word and sort the lane into its scatter class
         if (w.cur == WALK_FINISHED) {
             Hit hit;
