@@ -170,7 +170,7 @@ def main():
             "frac": ach / PEAK_FP32_VALU_TFLOPS, "traffic": None, "traffic_unit": "bytes/launch",
             "kernel": "pt_render_sched_kernel", "flops_per_ray": fl / cs["rays"], "rays_per_launch": cs["rays"],
             "nodes_per_ray": cs["nodes"] / cs["rays"], "sphere_tests_per_ray": cs["tests"] / cs["rays"],
-            "note": f"scene ({cs['scene_bytes'] / 1024:.0f} KB) is LDS-resident: bounded by FP32 VALU issue + LDS latency, not HBM; peak is the "
+            "note": f"scene ({cs['scene_bytes'] / 1024:.0f} KB) is LDS-resident: bounded by vector + scalar instruction issue (see valu_issue), not HBM; peak is the "
                     "vector FP32 figure (equal to the FP32 MFMA peak)",
             "scene_fetch": {"bytes_per_ray": by / cs["rays"], "achieved_GBps": by / (kernel_ms * 1e-3) / 1e9,
                             "served_from": "LDS" if cs["scene_in_lds"] else "L2/HBM", "hbm_peak_GBps": PEAK_HBM_GBS},
