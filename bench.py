@@ -190,6 +190,12 @@ def main():
                 "measured_peak_per_simd_per_s": MEASURED_VALU_ISSUE_PER_SIMD,
                 "frac": rate / MEASURED_VALU_ISSUE_PER_SIMD,
                 "active_lanes_per_instr": pc["SQ_THREAD_CYCLES_VALU"] / pc["SQ_INSTS_VALU"],
+                # the scalar unit is shared by the four SIMDs of a CU: with two vector instructions per scalar
+                # one, six waves per SIMD sustain 0.327 vector instructions per cycle instead of 0.38
+                # (tools/micro/valu_peak, profiles/r01_micro/valu_peak.txt)
+                "scalar_instr_per_launch": pc.get("SQ_INSTS_SALU"),
+                "vector_per_scalar": pc["SQ_INSTS_VALU"] / pc["SQ_INSTS_SALU"] if pc.get("SQ_INSTS_SALU") else None,
+                "measured_peak_at_2_to_1_mix_per_simd_per_s": 0.327 / 0.38 * MEASURED_VALU_ISSUE_PER_SIMD,
             }
         # ---- converged-image parity against the reference's own render (outside the timed region)
         if not args.no_rmse and os.path.basename(args.scene) == "scene1.ron":
