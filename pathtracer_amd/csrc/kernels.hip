@@ -428,7 +428,7 @@ __device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
 template <int SCENE, bool COUNT, int BLK>
-__global__ void __launch_bounds__(BLK) pt_render_sched_kernel(const RenderParams P) {
+__global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 1024 ? 8 : 1, 8))) pt_render_sched_kernel(const RenderParams P) {
     constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
@@ -1190,12 +1190,18 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
         // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
         // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
+        // Registers: the kernels need 70 vector registers (7 waves per SIMD: 28 per CU, 24 in whole 512-lane
+        // workgroups); the 1024-lane instance of the scheduled kernel is compiled for 64 (8 per SIMD, two
+        // workgroups per CU, one spilled register) -- more waves raise the instruction-issue ceiling the
+        // kernel runs at: scene1, 256 frames, 20.65 ms with 3 x 512 lanes per CU, 19.20 ms with 2 x 1024.
         auto waves_per_cu = [&](uint32_t blk) {
             size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk);
             size_t blocks = per_block ? lds_cu / per_block : 8;
-            return std::min<size_t>(blocks * (blk / 64), 24);  // 24: the register budget of these kernels
+            const size_t cap = blk == 1024 ? 32 : (blk == 512 ? 24 : 28);
+            return std::min<size_t>(blocks * (blk / 64), cap);
         };
         block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
+        if (!lockstep && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
         if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
         lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
     } else {
@@ -1205,13 +1211,13 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // 18.3 ms per 16 frames; everything in global memory 21.7 ms; a 64 KB prefix at 8 waves per CU
         // 33 ms (occupancy matters more than the size of the prefix).
         // MI355PT_STACK_LDS (entries) and MI355PT_NODE_CACHE_KB override the split (development).
-        block = 512u;
+        block = lockstep ? 512u : 1024u;  // the scheduled kernel's 1024-lane instance runs 8 waves per SIMD
         if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
         const uint32_t depth = std::max(1u, d->layout.max_depth);
         P.stack_lds_entries = (uint32_t)std::min<long>(depth, std::max<long>(1, env_int("MI355PT_STACK_LDS", 6)));
         P.stack_spill_entries = std::max(1u, depth - P.stack_lds_entries);
         const uint32_t stack_lds = P.stack_lds_entries * block * 4u;
-        const uint32_t blocks_per_cu = std::max(1u, 24u / (block / 64u));
+        const uint32_t blocks_per_cu = std::max(1u, (block == 1024u ? 32u : 24u) / (block / 64u));
         const long budget = (long)(lds_cu / blocks_per_cu) - (long)stack_lds - 2048;  // LDS is granted in granules
         long cache = env_int("MI355PT_NODE_CACHE_KB", -1) >= 0 ? env_int("MI355PT_NODE_CACHE_KB", -1) * 1024 : budget;
         cache = std::min<long>(cache, (long)lds_cu - (long)stack_lds);
