@@ -1175,6 +1175,9 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         P.chunk_max = d->scene_in_lds ? 32u : 4u;
         if (cenv && atoi(cenv) > 0) P.chunk_max = (uint32_t)std::min(1024, atoi(cenv));
     }
+    // Short launches (fewer than about a hundred 64-path units per resident wave: below 32 frames at 1920x1080)
+    // are a few per cent faster with the smaller workgroups; long ones 7 % faster with 1024 lanes at 8 waves per SIMD.
+    const bool long_launch = (uint64_t)std::min(n_frames, batch) * tiles >= 96ull * 32ull * (uint64_t)d->prop.multiProcessorCount;
     const bool in_lds = d->scene_in_lds;
     const int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
                            : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
@@ -1201,7 +1204,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
             return std::min<size_t>(blocks * (blk / 64), cap);
         };
         block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
-        if (!lockstep && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
+        if (!lockstep && long_launch && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
         if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
         lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
     } else {
@@ -1211,7 +1214,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // 18.3 ms per 16 frames; everything in global memory 21.7 ms; a 64 KB prefix at 8 waves per CU
         // 33 ms (occupancy matters more than the size of the prefix).
         // MI355PT_STACK_LDS (entries) and MI355PT_NODE_CACHE_KB override the split (development).
-        block = lockstep ? 512u : 1024u;  // the scheduled kernel's 1024-lane instance runs 8 waves per SIMD
+        block = (lockstep || !long_launch) ? 512u : 1024u;  // the scheduled kernel's 1024-lane instance runs 8 waves per SIMD
         if (benv == 256 || benv == 512 || benv == 1024) block = (uint32_t)benv;
         const uint32_t depth = std::max(1u, d->layout.max_depth);
         P.stack_lds_entries = (uint32_t)std::min<long>(depth, std::max<long>(1, env_int("MI355PT_STACK_LDS", 6)));
