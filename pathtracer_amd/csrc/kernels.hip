@@ -1163,7 +1163,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     const bool lockstep = kenv && strcmp(kenv, "lockstep") == 0;
     P.watchdog_ticks = 20ull * 100000000ull;  // 20 s
     P.inv_tiles_x = 1.0f / (float)tiles_x;
-    const uint32_t default_thr[6] = {16, 8, 24, 16, 8, 40};
+    const uint32_t default_thr[6] = {12, 8, 24, 16, 6, 32};
     for (int k = 0; k < 6; k++) P.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {
         unsigned t[6];
