@@ -80,7 +80,8 @@ typedef struct mi355pt_stats {
     uint32_t bvh_nodes;  /* interior nodes of the tree in use */
     uint32_t bvh_depth;  /* its depth */
     uint32_t scene_bytes;/* size of the device scene blob */
-    uint32_t scene_in_lds; /* 1 when the blob is staged in LDS by every workgroup */
+    uint32_t scene_in_lds; /* 1 when the blob is staged in LDS by every workgroup (small scenes; 0 under
+                              MI355PT_BVH_REFERENCE / mi355pt_set_bvh, whose walk reads global memory) */
     uint32_t node_format;  /* 0: 64-byte nodes, float boxes; 1: 32-byte nodes, binary16 boxes (LDS scenes only) */
 } mi355pt_stats;
 
