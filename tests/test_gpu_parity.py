@@ -7,11 +7,12 @@ sqrt), and per-frame results are added in frame order, so no tolerance is needed
 tolerance the design allows (>= 99.9 % of pixels within 1e-5 relative for one frame) is therefore
 never exercised and a single differing bit fails these tests.
 
-One exception, named in its test: the million-sphere plane.  There, ray-sphere roots of far, small
+One exception, named in its tests: the million- and ten-million-sphere planes.  There, ray-sphere roots of far, small
 spheres lose so many bits to cancellation that a root can be "found" for a ray that misses the
 sphere's padded box; whether such a root is ever computed depends on which boxes a walk tests, in
 the reference as much as here, so a few pixels per ten thousand (all on the horizon) depend on the
-tree.  That test uses the fallback bound: fewer than 0.1 % of pixels may differ.
+tree.  Those tests bound the pixels that differ with the default tree (under 0.1 % at a million spheres, under
+1 % at ten million) and require bit-identical results when the reference's own tree is walked the reference's way.
 """
 import json
 import os
@@ -363,6 +364,22 @@ def test_million_spheres_within_the_stated_bound(pa, orc):
     assert len(rows) <= 2                         # the horizon
     assert abs(int(gs["rays"]) - int(st["rays"])) <= 8
     # walking the reference's own tree the reference's way leaves no such pixel
+    acc_r, gs_r = gpu_render(pa, sc, W, H, seeds, bvh_mode=pa.BVH_REFERENCE)
+    assert bits_equal(ref, acc_r) and gs_r["rays"] == st["rays"]
+
+
+def test_ten_million_spheres_reference_walk(pa, orc):
+    # 680 MB blob, a 26-level tree.  With the default tree 0.2 % of the pixels of this scene depend on the tree
+    # (far, tiny spheres; see the module docstring); walking the reference's tree the reference's way leaves none.
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(10_000_000)
+    osc = oracle_scene(orc, sc)
+    W, H = 96, 54
+    seeds = [11, 22]
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, seeds)
+    differ = (acc.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
+    assert differ.sum() * 100 < W * H              # under 1 % with the default tree
     acc_r, gs_r = gpu_render(pa, sc, W, H, seeds, bvh_mode=pa.BVH_REFERENCE)
     assert bits_equal(ref, acc_r) and gs_r["rays"] == st["rays"]
 
