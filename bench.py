@@ -90,7 +90,10 @@ def main():
     if backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # MI355PT_BENCH_DIST=1 under a one-rank torchrun takes the multi-rank code path (process group, reduce,
+    # all-reduces) with a world of one: the only RCCL rehearsal a one-GPU box allows
+    use_dist = world > 1 or os.environ.get("MI355PT_BENCH_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -102,7 +105,7 @@ def main():
     settings = pa.Settings(1, 50)
     base_seed = 0x00C0FFEE
     r = pa.Renderer(scene, settings, W, H, device=local_rank, base_seed=base_seed)
-    acc_t = parallel.accum_tensor(r, local_rank) if world > 1 else None
+    acc_t = parallel.accum_tensor(r, local_rank) if use_dist else None
 
     def step_seeds(step):
         # global frame index: steps interleave ranks so every rank's frames are disjoint
@@ -111,13 +114,13 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
     for s in range(args.warmup):
         r.render(seeds=step_seeds(args.steps + s))
-    if world > 1 and args.warmup:
+    if use_dist and args.warmup:
         parallel.reduce_accum(torch.zeros_like(acc_t), world, dst=0)  # communicator set-up outside the timed region
     r.clear()
     sync()
@@ -125,18 +128,18 @@ def main():
     for s in range(args.steps):
         r.render(seeds=step_seeds(s), wait=False)   # a step's accumulation overlaps the next step's path kernel
     r.wait()
-    if world > 1:
+    if use_dist:
         parallel.reduce_accum(acc_t, world, dst=0)
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     st = r.stats()
     counts = torch.tensor([st["paths"], st["rays"]], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
     paths_all, rays_all = float(counts[0].item()), float(counts[1].item())
 
@@ -240,7 +243,7 @@ def main():
             }
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -36,7 +36,8 @@ def reduce_accum(tensor, world, dst=0):
     """Sum-reduce accumulators to `dst` (RCCL when the tensor is on a GPU, gloo on the CPU) and restore
     the constant alpha of the reference's texture (every rank cleared its own to 1)."""
     import torch.distributed as dist
-    if world > 1:
+    grouped = world > 1 or (dist.is_available() and dist.is_initialized())   # a group of one still reduces
+    if grouped:
         if tensor.is_cuda and dist.get_backend() == "gloo":  # gloo reduces host tensors only
             host = tensor.cpu()
             dist.reduce(host, dst=dst, op=dist.ReduceOp.SUM)
@@ -44,7 +45,7 @@ def reduce_accum(tensor, world, dst=0):
                 tensor.copy_(host)
         else:
             dist.reduce(tensor, dst=dst, op=dist.ReduceOp.SUM)
-    if dist.get_rank() == dst if world > 1 else True:
+    if dist.get_rank() == dst if grouped else True:
         tensor[..., 3] = 1.0
     return tensor
 
