@@ -244,6 +244,7 @@ def main():
         print(json.dumps(out), flush=True)
     r.close()
     if use_dist:
+        dist.barrier()   # rank 0's reporting legs are over: all ranks leave the group together
         dist.destroy_process_group()
 
 
