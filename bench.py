@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak): 256 CUs x 128 FMA lanes x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 # rocprofv3 summary of this command (tools/profile.sh): source of roofline.traffic and of the issue-slot figure
-PROFILE = os.path.join("profiles", "r01_v13_final", "pmc_summary.json")
+PROFILE = os.path.join("profiles", "r01_v14_final", "pmc_summary.json")
 # highest sustained vector issue rate measured on MI355X (tools/micro/valu_peak, profiles/r01_micro/valu_peak.txt)
 MEASURED_VALU_ISSUE_PER_SIMD = 9.07e8   # wave-instructions / s / SIMD
 

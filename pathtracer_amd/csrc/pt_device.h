@@ -344,6 +344,19 @@ inline float half_lo(uint32_t u) { return half_bits_to_float(u & 0xffffu); }
 inline float half_hi(uint32_t u) { return half_bits_to_float(u >> 16); }
 #endif
 
+// fminf(a, b) for a `b` that is never a signalling NaN (the closest hit so far: infinity or a computed
+// root).  The plain call makes the compiler quiet `b` first, one more vector instruction per node; the
+// instruction itself returns the same value for every such pair.
+#if defined(__HIP_DEVICE_COMPILE__)
+PT_FN float fmin_quiet(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+#else
+inline float fmin_quiet(float a, float b) { return fminf(a, b); }
+#endif
+
 template <class Mem, class Stack, bool COUNT, bool HALF>
 PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, Counters& cnt) {
     float t0, t1;
@@ -360,9 +373,9 @@ PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
         t1 = fmaxf(fmaxf(PT_FMA(ax.y, w.inv.x, -w.ood.x), PT_FMA(ay.y, w.inv.y, -w.ood.y)),
                    fmaxf(PT_FMA(az.y, w.inv.z, -w.ood.z), 0.0f));
         const float f0 = fminf(fminf(PT_FMA(ax.z, w.inv.x, -w.ood.x), PT_FMA(ay.z, w.inv.y, -w.ood.y)),
-                               fminf(PT_FMA(az.z, w.inv.z, -w.ood.z), w.best_t));
+                               fmin_quiet(PT_FMA(az.z, w.inv.z, -w.ood.z), w.best_t));
         const float f1 = fminf(fminf(PT_FMA(ax.w, w.inv.x, -w.ood.x), PT_FMA(ay.w, w.inv.y, -w.ood.y)),
-                               fminf(PT_FMA(az.w, w.inv.z, -w.ood.z), w.best_t));
+                               fmin_quiet(PT_FMA(az.w, w.inv.z, -w.ood.z), w.best_t));
         h0 = t0 <= f0, h1 = t1 <= f1;
         c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
     } else if constexpr (HALF) {
