@@ -15,11 +15,41 @@ namespace gpu {
 
 constexpr uint32_t RAY_SLOTS = 64, RAY_SLOT_STRIDE = 16;  // 64 ray counters, 128 bytes apart
 
+// Makes `id` the calling thread's current device for the lifetime of the guard and puts the caller's
+// device back afterwards: a host that also drives HIP (or torch) on another device keeps its own.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int id) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != id) (void)hipSetDevice(id);
+        else prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+// Development switches (environment variables, not part of the ABI), read once when a context is created.
+struct Switches {
+    uint32_t max_batch = 0;    // MI355PT_MAX_BATCH: frames per launch (0: up to 4096)
+    uint32_t block = 0;        // MI355PT_BLOCK: workgroup size 256 | 512 | 1024 (0: chosen per launch)
+    long stack_lds = 6;        // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
+    long node_cache_kb = -1;   // MI355PT_NODE_CACHE_KB: node prefix kept in LDS for those scenes (-1: what fits)
+    bool tile_order = true;    // MI355PT_TILE_ORDER=0: tiles in row-major order
+    uint32_t ring_slots = 32;  // MI355PT_RING_SLOTS: rows in flight per wave
+    uint64_t watchdog_ms = 20000;  // MI355PT_WATCHDOG_MS
+    uint32_t job_frames_min = 4, job_frames_max = 32;  // MI355PT_JOB_FRAMES_MIN / _MAX: frames per job
+    uint32_t thr[6] = {12, 8, 24, 16, 6, 32};  // MI355PT_SCHED: step thresholds node, leaf, -, opaque, glass, restart
+};
+
 struct Device {
     int id = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipDeviceProp_t prop;
+    Switches sw;
 
     char* scene = nullptr;
     size_t scene_cap = 0;
@@ -30,16 +60,14 @@ struct Device {
     uint32_t width = 0, height = 0, n_pix = 0;
     f4* accum = nullptr;
     uint32_t* pixel_hash = nullptr;
-    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
-    // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
-    // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
-    // way of the persistent kernel's workgroup placement.)
-    f4* frame_buf = nullptr;
-    size_t frame_cap = 0;  // in f4 elements
-    // Cost-ordered work: rays per tile of the last launch, tiles sorted by it, and what it was measured for
+    // Colours of finished paths on their way to the accumulator: per resident wave a few slots of 64 x 3
+    // floats (see kernels.hip); the slots in use stay in the L2.
+    float* ring = nullptr;
+    size_t ring_cap = 0;  // bytes
+    // Cost-ordered work: rays per tile of the last measuring launch, tiles sorted by it, and what it was measured for
     float* tile_cost = nullptr;    // [tiles]
     uint32_t* tile_perm = nullptr; // [tiles]
-    uint16_t* rank_chunk = nullptr; // [tiles] chunk size for a chunk that starts in the tile of that rank
+    uint32_t* tile_done = nullptr; // [tiles] ranges of the tile added so far during a launch
     bool perm_valid = false;
     uint32_t since_measure = 0;  // launches since the tile costs were last measured
     Camera64 perm_cam{};
@@ -49,9 +77,8 @@ struct Device {
     std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
     struct Timed {
         hipEvent_t begin, end;
-        bool resolve;
     };
-    std::vector<Timed> timed;          // launches enqueued since the last finish()
+    std::vector<Timed> timed;          // launches enqueued since the last finish(), both events recorded
     std::vector<hipEvent_t> event_pool;
     bool in_flight = false;
     uint64_t pending_paths = 0;
@@ -59,8 +86,8 @@ struct Device {
     int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
     size_t spill_cap = 0;            // in entries
     uint32_t* work_counter = nullptr;  // [1]
-    unsigned long long* counters = nullptr;  // [8] kernel counters, watchdog, step statistics
-    unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] ray totals of the accumulation kernel
+    unsigned long long* counters = nullptr;  // [32] kernel counters, watchdog, step statistics
+    unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] rays traced, striped
 };
 
 #define PT_HIP(call)                                                                          \

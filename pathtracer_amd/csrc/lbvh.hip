@@ -271,7 +271,7 @@ struct Scratch {  // device allocations of one build, released on every exit pat
 bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std::string& err) {
     if (!validate_scene(a, err)) return false;
     const uint32_t n = (uint32_t)a.n_spheres;
-    PT_HIP(hipSetDevice(d->id));
+    DeviceGuard guard(d->id);
     PT_HIP(hipStreamSynchronize(d->stream));
     hipStream_t st = d->stream;
 
