@@ -33,16 +33,22 @@ struct DeviceGuard {
 
 // Development switches (environment variables, not part of the ABI), read once when a context is created.
 struct Switches {
-    uint32_t max_batch = 0;    // MI355PT_MAX_BATCH: frames per launch (0: up to 4096)
-    uint32_t block = 0;        // MI355PT_BLOCK: workgroup size 256 | 512 | 1024 (0: chosen per launch)
-    long stack_lds = 6;        // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
-    long node_cache_kb = -1;   // MI355PT_NODE_CACHE_KB: node prefix kept in LDS for those scenes (-1: what fits)
-    bool tile_order = true;    // MI355PT_TILE_ORDER=0: tiles in row-major order
-    uint32_t ring_slots = 32;  // MI355PT_RING_SLOTS: rows in flight per wave
+    uint32_t max_batch = 0;     // MI355PT_MAX_BATCH: frames per launch (0: what the frame buffer holds)
+    uint32_t frame_buf_gb = 0;  // MI355PT_FRAME_BUF_GB: frame buffer budget (0: FRAME_BUF_DEFAULT_BYTES)
+    uint32_t block = 0;         // MI355PT_BLOCK: workgroup size 256 | 512 | 1024 (0: chosen per launch)
+    long stack_lds = 6;         // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
+    long node_cache_kb = -1;    // MI355PT_NODE_CACHE_KB: node prefix kept in LDS for those scenes (-1: what fits)
+    bool tile_order = true;     // MI355PT_TILE_ORDER=0: tiles in row-major order
+    uint32_t chunk = 0;         // MI355PT_CHUNK: largest work-queue chunk in units (0: 32 for LDS scenes, else 4)
+    float chunk_share = 2.0f;   // MI355PT_CHUNK_SHARE
+    float chunk_rays = 2600.0f; // MI355PT_CHUNK_RAYS
+    bool lockstep = false;      // MI355PT_KERNEL=lockstep: the simple kernel
     uint64_t watchdog_ms = 20000;  // MI355PT_WATCHDOG_MS
-    uint32_t job_frames_min = 4, job_frames_max = 32;  // MI355PT_JOB_FRAMES_MIN / _MAX: frames per job
     uint32_t thr[6] = {12, 8, 24, 16, 6, 32};  // MI355PT_SCHED: step thresholds node, leaf, -, opaque, glass, restart
 };
+// Results of one launch wait in a frame buffer for the accumulation kernel; it is at most this large (and at
+// most a quarter of the free device memory): 334 frames at 1920x1080, 84 at 3840x2160.
+constexpr size_t FRAME_BUF_DEFAULT_BYTES = (size_t)8 << 30;
 
 struct Device {
     int id = 0;
@@ -60,14 +66,16 @@ struct Device {
     uint32_t width = 0, height = 0, n_pix = 0;
     f4* accum = nullptr;
     uint32_t* pixel_hash = nullptr;
-    // Colours of finished paths on their way to the accumulator: per resident wave a few slots of 64 x 3
-    // floats (see kernels.hip); the slots in use stay in the L2.
-    float* ring = nullptr;
-    size_t ring_cap = 0;  // bytes
+    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
+    // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
+    // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
+    // way of the persistent kernel's workgroup placement.)
+    f4* frame_buf = nullptr;
+    size_t frame_cap = 0;  // in f4 elements
     // Cost-ordered work: rays per tile of the last measuring launch, tiles sorted by it, and what it was measured for
     float* tile_cost = nullptr;    // [tiles]
     uint32_t* tile_perm = nullptr; // [tiles]
-    uint32_t* tile_done = nullptr; // [tiles] ranges of the tile added so far during a launch
+    uint16_t* rank_chunk = nullptr; // [tiles] chunk size for a chunk that starts in the tile of that rank
     bool perm_valid = false;
     uint32_t since_measure = 0;  // launches since the tile costs were last measured
     Camera64 perm_cam{};
@@ -77,6 +85,7 @@ struct Device {
     std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()
     struct Timed {
         hipEvent_t begin, end;
+        bool resolve;
     };
     std::vector<Timed> timed;          // launches enqueued since the last finish(), both events recorded
     std::vector<hipEvent_t> event_pool;

@@ -1,13 +1,14 @@
 // HIP kernels for gfx950 (MI355X) and their launch code.
 //
 //   pt_hash_kernel          per-pixel seed hash (compute.wgsl:392-400), once per resize
-//   pt_render_sched_kernel  persistent path kernel: a wave owns one 8x8-pixel tile at a time for ALL frames of
-//                           the launch; every lane traces one (pixel, frame) path at a time and takes the next
-//                           one of the wave's tile the moment its path ends; the wave runs one kind of step at a
-//                           time (node / leaf / scatter / restart), chosen by how many lanes wait for it; finished
-//                           paths park their colour in a small per-wave ring (L2-resident) and the wave adds
-//                           completed frames to the accumulator in frame order (compute.wgsl:418-421), which
-//                           keeps sums bit-identical to a frame-by-frame run
+//   pt_render_sched_kernel  persistent path kernel (default): every lane owns one (pixel, frame) path at a
+//                           time and pulls a new one from a work queue the moment its path ends; the wave
+//                           runs one kind of step at a time (node / leaf / scatter / restart), chosen by
+//                           how many lanes wait for it
+//   pt_render_kernel        the same paths in plain lockstep (acquire -> camera -> whole BVH walk ->
+//                           scatter per iteration); kept as the simple reference for the scheduled one
+//   pt_resolve_kernel       adds the per-frame results to the accumulator in frame order
+//                           (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
 //   pt_tile_order_kernel    orders the 8x8 tiles by the rays they cost in the last launch
 #include <hip/hip_runtime.h>
 
@@ -25,6 +26,22 @@
 
 namespace pt {
 namespace gpu {
+
+// Work queue: waves take chunks of 64-path units from one counter.  One returning atomic per chunk on a
+// single address is a device-wide serial resource: with fixed 4-unit chunks it cost 10 % of a scene1
+// launch on MI355X (65 M atomics/s) and two thirds of a scene2 launch.  Chunks are therefore up to
+// RenderParams::chunk_max units while plenty of work is left and shrink towards the end of the queue,
+// where balance matters: chunk = what is left / (2 * waves), clamped to [1, chunk_max]; once tile costs
+// are known, a chunk is also limited to about 2 600 rays (rank_chunk), because the expensive tiles come
+// first and a 32-unit chunk of them keeps one wave busy for 6 ms.  The host sets
+// chunk_max to 32 for scenes in LDS and to 4 for scenes in global memory: there the waves should stay
+// close together in the image, so that the part of the tree they walk stays in the caches (10 M spheres
+// at 3840x2160: 13.0 ms per 8 frames with 4-unit chunks, 28 ms with 32-unit chunks).
+__device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t taken_to, float inv_share,
+                                                       uint32_t chunk_max) {
+    const uint32_t left = total - min(total, taken_to);
+    return max(1u, min(chunk_max, (uint32_t)((float)left * inv_share)));
+}
 
 #define PT_LDS(T) __attribute__((address_space(3))) T
 
@@ -127,69 +144,38 @@ struct SpillStack {
     }
 };
 
-
-// Work and results.  A job is one 8x8-pixel tile for a range of job_frames consecutive frames of the launch; the
-// 64 paths of one (tile, frame) form a row.  Jobs are numbered range-major -- job j = (range j / n_tiles, tile
-// tile_perm[j % n_tiles]) -- and taken from one atomic counter, one at a time.  A wave hands the paths of
-// consecutive rows to its lanes as they fall idle, so at any moment its lanes hold paths of a few consecutive
-// frames of one tile (and of the next job while the last paths of the previous one finish).
-//
-// Frames must reach a texel in frame order (compute.wgsl:418-421 runs once per frame; float addition does not
-// commute bit for bit), but paths finish out of order.  A finished path therefore parks its colour in the slot of
-// its row in the wave's ring -- MAX_RING_SLOTS slots of 64 x 3 floats in global memory, private to the wave, taken
-// lowest-free-first so that the few slots in use stay in the L2 -- and counts the row's pending paths down in
-// LDS.  At each restart step the wave adds the rows that are complete, oldest first, to the tile's sums: lane p
-// adds pixel p.  The sums live in the accumulator before and after a job and in a private row of the wave (one more
-// ring slot) in between, so a job reads and writes each of its texels in the accumulator once.
-//
-// Ranges of one tile must be added in order too, and they are different jobs, usually of different waves on
-// different XCDs.  The queue's order makes the wait vanish: job (range k, tile t) comes n_tiles jobs after
-// (range k - 1, tile t), by which time the latter is normally long done.  The hand-off itself is explicit: the wave
-// that finishes range k - 1 stores the texels with sc1 (write-through) stores, waits for them (s_waitcnt vmcnt(0))
-// and then raises tile_done[t] to k with an agent-scope store; the wave that owns range k polls tile_done[t] with
-// an agent-scope load before its first commit -- it keeps its finished rows in the ring until then -- and reads
-// the texels with sc1 loads (every texel load in the kernel is one: no stale L1 line is ever used).  A job only
-// ever waits for a job with a smaller number, so the smallest unfinished job can always finish.
-constexpr uint32_t MAX_RING_SLOTS = 32;                   // rows in flight per wave (a 51-ray path spans ~25)
-constexpr uint32_t ROW_PIXELS = 64;                       // 8 x 8
-constexpr uint32_t RING_SLOT_FLOATS = ROW_PIXELS * 3u;    // rgb per pixel
-constexpr uint32_t RING_WAVE_FLOATS = MAX_RING_SLOTS * RING_SLOT_FLOATS + ROW_PIXELS * 4u;  // + the private sums row
-// per wave and row in flight: {tile x | tile y << 13 | slot << 26 | last row of its job << 31, pending paths,
-// rays traced, range index of the job}
-constexpr uint32_t ROWS_LDS_BYTES = MAX_RING_SLOTS * 16u;
-
 struct RenderParams {
     const char* scene;
     SceneLayout L;
     Camera64 cam;
-    uint32_t width, height, tiles_x, n_tiles;
+    uint32_t width, height, tiles_x, tiles_per_frame, n_pix;
     int32_t samples, depth;
-    uint32_t n_frames;             // frames of this launch
-    uint32_t job_frames;           // frames per job
-    uint32_t n_ranges;             // ceil(n_frames / job_frames); jobs = n_ranges * n_tiles
-    float inv_n_tiles;
-    // Job j renders tile tile_perm[j % n_tiles] (or j % n_tiles without a permutation).  The permutation lists
-    // tiles by decreasing measured cost, so within every range the expensive tiles start first and the queue ends
-    // with the cheapest ones.
+    uint32_t total_units;  // frames in this launch * tiles_per_frame
+    // Work order: unit u = (tile rank u / n_frames, frame u % n_frames); tile = tile_perm[rank] (or the
+    // rank itself without a permutation).  The permutation lists tiles by decreasing measured cost, so
+    // the long paths start early and the queue ends with the cheapest tiles.
+    uint32_t n_frames;
+    float inv_n_frames;
     const uint32_t* tile_perm;
-    uint32_t* tile_done;           // [n_tiles] ranges of the tile added to the accumulator so far (zero at launch)
-    const uint32_t* seeds;         // one per frame of this launch
-    const uint32_t* pixel_hash;    // [width * height]
-    f4* accum;                     // [width * height]
-    float* ring;                   // [waves of the grid][RING_WAVE_FLOATS]
-    uint32_t ring_slots;           // slots in use, <= MAX_RING_SLOTS
-    float* tile_cost;              // rays traced per tile, added up over the jobs (may be null; zero at launch)
+    const uint16_t* rank_chunk;  // with tile_perm: chunk size by the rank the chunk starts in (cost-aware)
+    const uint32_t* seeds;       // one per frame of this launch
+    const uint32_t* pixel_hash;  // [n_pix]
+    f4* frame_out;               // [frame][tile rank][slot]: rgb = final_colour / samples, w = rays traced;
+                                 // with `compact`: three floats per result, no ray count
+    uint32_t compact;            // 1: 12-byte results; the rays traced are summed per wave into ray_slots instead
+                                 // (launches that measure the tile costs need the count per path: 16-byte results)
     unsigned long long* ray_slots;
     uint32_t* work_counter;
-    unsigned long long* counters;  // nodes, tests, accepted, bounce[5], -, -, watchdog, ...; from 16: step statistics
+    unsigned long long* counters;  // nodes, tests, accepted, bounce[5]
     uint32_t scene_lds_bytes;
-    uint32_t rows_lds_off;         // byte offset from the workgroup's LDS base to the waves' row tables
     int32_t glass_always_draws;
     uint64_t watchdog_ticks;  // 100 MHz ticks without a finished path after which a wave gives up (scheduling-bug guard)
-    uint32_t thr[6];  // lanes that must wait for a step before it runs: node, leaf, (unused: terminal lanes are
-                      // served by the restart step), opaque, glass, restart
+    uint32_t thr[6];  // pt_render_sched_kernel: lanes that must wait for a step before it runs: node, leaf,
+                      // (unused: terminal lanes are served by the restart step), opaque, glass, restart
     float inv_tiles_x;
-    uint32_t small_ids;  // 1: job and tile ids < 2^24 (divmod24 is exact)
+    uint32_t small_ids;  // 1: unit and tile ids < 2^24 (divmod24 is exact)
+    float inv_share;  // 1 / (2 * waves in the grid), for the chunk size
+    uint32_t chunk_max;
     // SCENE_GLOBAL only: scene_lds_bytes is the node prefix kept in LDS, the stack keeps
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
     int32_t* stack_spill;
@@ -248,24 +234,178 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
     __syncthreads();
 }
 
-// At the end of a path kernel: the rays the wave traced, one atomic per wave on a striped counter.
+// One finished pixel-frame.
+__device__ __forceinline__ void store_result(const RenderParams& P, uint32_t index, f4 rgb, uint32_t rays, uint32_t& lane_rays) {
+    if (P.compact) {
+        float* o = reinterpret_cast<float*>(P.frame_out) + (size_t)index * 3u;
+        o[0] = rgb.x, o[1] = rgb.y, o[2] = rgb.z;
+        lane_rays += rays;
+    } else {
+        rgb.w = (float)rays;  // summed per pixel by the accumulation kernel: ray total and tile costs
+        P.frame_out[index] = rgb;
+    }
+}
+// At the end of a path kernel: the rays of a compact launch, one atomic per wave on a striped counter.
 __device__ __forceinline__ void flush_rays(const RenderParams& P, uint32_t lane_rays) {
+    if (!P.compact) return;
     const unsigned long long total = wave_sum((unsigned long long)lane_rays);
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if ((threadIdx.x & 63u) == 0 && total) atomicAdd(P.ray_slots + (size_t)(wave % RAY_SLOTS) * RAY_SLOT_STRIDE, total);
 }
 
-__device__ __forceinline__ uint32_t uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+template <int SCENE, bool COUNT, int BLK>
+__global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
+    constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
+    extern __shared__ __align__(16) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
+    stage_scene<SCENE, BLK>(P, lds0);
+    using Mem = typename SceneMem<SCENE>::type;
+    using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
+    Mem mem;
+    Stack stack;
+    stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
+    if constexpr (SCENE == SCENE_LDS) {
+        mem.node_base = lds0;
+        mem.base = lds0 + P.L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+    } else if constexpr (LDS_SCENE) {
+        mem.base = lds0;
+    } else {
+        mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
+        stack.spill = P.stack_spill + (size_t)blockIdx.x * P.stack_spill_entries * BLK + threadIdx.x;
+        stack.lds_entries = (int32_t)P.stack_lds_entries;
+    }
 
-// Every lane is a small state machine kept in Walk::cur -- interior node pending, leaf pending, walk
-// finished, one of three scatter classes pending, idle (needs a path or a camera ray), exited -- and the
-// wave runs one kind of step at a time, only when enough lanes wait for it (ballot + popcount against a
-// threshold).  Lanes in a thinly populated state wait until their state fills up, so the long scatter
-// bodies run with many lanes active instead of being serialised over sparsely populated material
-// branches, and the node loop stops when its population drops below the threshold instead of dragging a
-// few long walks along with most lanes idle.  When no state reaches its threshold every non-empty state
-// runs once, which guarantees progress.  Scheduling only reorders work between independent paths; every
-// path performs exactly the arithmetic of compute.wgsl's trace_path.
+    const CameraRegs cam = load_camera(P.cam);
+    const float fw = (float)P.width, fh = (float)P.height;
+    const uint32_t lane = threadIdx.x & 63u;
+
+    // lane state
+    bool alive = false, need_ray = false;
+    PathState ps;
+    ps.o = ps.d = ps.colour = mk(0.0f, 0.0f, 0.0f);
+    ps.rng = 1u;
+    ps.bounce = 0;
+    V3 final_colour = mk(0.0f, 0.0f, 0.0f);
+    uint32_t out_index = 0, pxy = 0, nrays = 0, lane_rays = 0;
+    int32_t sample_i = 0;
+    Counters cnt = {0, 0, 0};
+    uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
+
+    // wave state (uniform)
+    uint32_t next = 0, end = 0;
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_share, P.chunk_max);
+    bool exhausted = false;
+
+    for (;;) {
+        // ---- acquire: idle lanes take consecutive path ids from the wave's chunk of the queue
+        unsigned long long m = __ballot(!alive);
+        while (m) {
+            if (next == end) {
+                if (exhausted) break;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(P.work_counter, chunk);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // lane 0 is active here: the step is entered by the whole wave
+                if (base >= P.total_units) {
+                    exhausted = true;
+                    break;
+                }
+                next = base * 64u;
+                end = min(base + chunk, P.total_units) * 64u;
+                chunk = guided_chunk_units(P.total_units, base + chunk, P.inv_share, P.chunk_max);
+            }
+            const uint32_t avail = end - next;
+            const uint32_t rank = lane_rank(m);
+            if (!alive && rank < avail) {
+                const uint32_t pid = next + rank;
+                const uint32_t unit = pid >> 6, slot = pid & 63u;
+                const uint32_t tile_rank = unit / P.n_frames;
+                const uint32_t frame = unit - tile_rank * P.n_frames;
+                const uint32_t tile = P.tile_perm ? P.tile_perm[tile_rank] : tile_rank;
+                const uint32_t result_index = (frame * P.tiles_per_frame + tile_rank) * 64u + slot;
+                uint32_t px, py;
+                tile_pixel(tile, slot, P.tiles_x, px, py);
+                if (px < P.width && py < P.height) {
+                    const uint32_t pix = py * P.width + px;
+                    ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
+                    out_index = result_index;
+                    pxy = px | (py << 16);
+                    final_colour = mk(0.0f, 0.0f, 0.0f);
+                    sample_i = 0;
+                    nrays = 0;
+                    alive = true;
+                    need_ray = true;
+                }
+            }
+            next += min((uint32_t)__popcll(m), avail);
+            m = __ballot(!alive);
+        }
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- camera: compute.wgsl:405-413
+        if (alive && need_ray) {
+            ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
+            ps.o = cam.pos;
+            ps.colour = mk(1.0f, 1.0f, 1.0f);
+            ps.bounce = 0;
+            need_ray = false;
+        }
+
+        // ---- extend + scatter
+        if (alive) {
+            Hit hit;
+            closest_hit<Mem, Stack, COUNT, HALF, SCENE == SCENE_REFERENCE>(mem, P.L, stack, ps.o, ps.d, hit, cnt);
+            nrays++;
+            V3 radiance;
+            uint32_t mat;
+            const bool done = scatter(mem, P.L, hit, ps, P.depth, P.glass_always_draws != 0, radiance, mat);
+            if (COUNT) {
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (mat == k) ? 1u : 0u;
+            }
+            if (done) {
+                final_colour = final_colour + radiance;
+                sample_i++;
+                if (sample_i < P.samples) {
+                    need_ray = true;
+                } else {
+                    f4 o4;
+                    o4.x = final_colour.x, o4.y = final_colour.y, o4.z = final_colour.z;
+                    if (P.samples != 1) {  // x / 1.0f == x: the common case needs no division
+                        const float fs = (float)P.samples;
+                        o4.x = final_colour.x / fs;
+                        o4.y = final_colour.y / fs;
+                        o4.z = final_colour.z / fs;
+                    }
+                    o4.w = 0.0f;
+                    store_result(P, out_index, o4, nrays, lane_rays);
+                    alive = false;
+                }
+            }
+        }
+    }
+
+    flush_rays(P, lane_rays);
+    if (COUNT) {
+        unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
+                                   bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            unsigned long long s = wave_sum(v[k]);
+            if (lane == 0) atomicAdd(&P.counters[k], s);
+        }
+    }
+}
+
+// Wave-scheduled variant.  Every lane is a small state machine kept in Walk::cur -- interior node
+// pending, leaf pending, walk finished, one of three scatter classes pending, idle (needs a path or a
+// camera ray), exited -- and the wave runs one kind of step at a time, only when enough lanes wait
+// for it (ballot + popcount against a threshold).  Lanes in a thinly populated state wait until their
+// state fills up, so the long scatter bodies run with many lanes active instead of being serialised
+// over sparsely populated material branches, and the node loop stops when its population drops below
+// the threshold instead of dragging a few long walks along with most lanes idle.  When no state
+// reaches its threshold every non-empty state runs once, which guarantees progress.  Scheduling only
+// reorders work between independent paths; every path performs exactly the arithmetic of the
+// lockstep kernel.
 // (All per-lane state lives in vector registers: a bool per lane would be a lane mask in a scalar register
 // pair, updated with three scalar instructions per nested branch, and the scalar unit is the scarcer one.)
 constexpr int32_t LANE_IDLE = INT32_MIN + 1;      // needs a path
@@ -312,11 +452,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     const CameraRegs cam = load_camera(P.cam);
     const float fw = (float)P.width, fh = (float)P.height;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave_in_block = uniform(threadIdx.x >> 6);
-    // the wave's row table in LDS and its ring in global memory
-    const uint32_t rows_lds = lds0 + P.rows_lds_off + wave_in_block * ROWS_LDS_BYTES;
-    float* const ring = P.ring + (size_t)(blockIdx.x * (BLK / 64) + wave_in_block) * RING_WAVE_FLOATS;
-    f4* const sums_row = reinterpret_cast<f4*>(ring + MAX_RING_SLOTS * RING_SLOT_FLOATS) + lane;  // this lane's private sums
 
     PathState ps;
     ps.o = ps.d = ps.colour = mk(0.0f, 0.0f, 0.0f);
@@ -327,112 +462,35 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     w.cur = LANE_IDLE;
     uint32_t mbits = 0;  // material word of the hit, valid in the scatter states
     V3 final_colour = mk(0.0f, 0.0f, 0.0f);
-    // path tag: pixel slot of the tile (6 bits) | ring slot << 6 (5 bits) | row-table index << 11 (5 bits)
-    uint32_t tag = 0, pxy = 0, rays = 0;  // rays of the lane's current path
-    uint32_t lane_rays = 0;               // rays of all its finished paths
+    uint32_t out_index = 0, pxy = 0, rays = 0;  // rays of the lane's current path
+    uint32_t lane_rays = 0;                     // rays of all its finished paths (compact launches)
     int32_t sample_i = 0;
     Counters cnt = {0, 0, 0};
     uint32_t bounce_cnt[5] = {0, 0, 0, 0, 0};
     uint32_t ph_exec[PH_COUNT] = {0}, ph_lanes[PH_COUNT] = {0};  // COUNT: wave-level step executions
 
-    // wave-uniform: rows issued / committed so far, free ring slots, the row and job being issued
-    uint32_t i_seq = 0, c_seq = 0;
-    uint32_t free_mask = P.ring_slots >= 32u ? 0xffffffffu : (1u << P.ring_slots) - 1u;
-    uint32_t row_next = ROW_PIXELS;   // pixel slots of the open row already handed out (ROW_PIXELS: no open row)
-    uint32_t row_tag = 0;             // ring slot << 6 | row-table index << 11 of the open row
-    uint32_t tile_xy = 0;             // tile x | tile y << 13 of the job being issued
-    uint32_t f_issue = 0, f_end = 0;  // its next frame and the end of its range (equal: a new job is needed)
-    uint32_t k_issue = 0;             // its range index
-    uint32_t seed_cur = 0;
-    bool exhausted = false, stalled = false;
-    bool c_first = true;              // the next row to commit is the first of its job
-    uint32_t job_rays = 0;            // rays of the committed rows of the job being committed
+    uint32_t next = 0, end = 0;  // wave-uniform: the wave's chunk of the path queue
+    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_share, P.chunk_max);
+    if (P.rank_chunk) chunk = min(chunk, (uint32_t)P.rank_chunk[0]);
+    bool exhausted = false;
     bool force = false;
-    uint64_t t_progress = __builtin_amdgcn_s_memrealtime();  // 100 MHz; when a path of this wave last finished
 
-    // Adds the rows that are complete, oldest first, to the sums of their tile (lane p: pixel p).
-    auto try_commit = [&]() {
-        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
-        bool have = false, a_ok = false;   // have: `a` holds the running sums of the job being committed
-        uint32_t a_idx = 0;
-        f4 a = {0.0f, 0.0f, 0.0f, 0.0f};
-        while (c_seq != i_seq) {
-            const w4 rec = *reinterpret_cast<const PT_LDS(w4)*>(rows_lds + (c_seq & (MAX_RING_SLOTS - 1u)) * 16u);
-            if (uniform(rec.y)) break;  // paths pending
-            const uint32_t info = uniform(rec.x), row_rays = uniform(rec.z), k = uniform(rec.w);
-            const uint32_t tx = info & 0x1fffu, ty = (info >> 13) & 0x1fffu, slot = (info >> 26) & 31u;
-            const bool last = (info >> 31) != 0u;
-            const uint32_t tile = ty * P.tiles_x + tx;
-            if (!have) {
-                if (c_first && k) {  // ranges 0 .. k-1 of this tile must be in the accumulator: one poll, no spinning
-                    if (__hip_atomic_load(P.tile_done + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < k) break;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drops this CU's L1 lines; the texel loads below are sc1 besides
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the wave's own result stores are in L2
-                const uint32_t px = tx * 8u + (lane & 7u), py = ty * 8u + (lane >> 3);
-                a_ok = px < P.width && py < P.height;
-                a_idx = py * P.width + px;
-                if (a_ok) {
-                    // texels: sc1 loads only (written by another wave's sc1 stores, or before the launch);
-                    // the private sums: this wave's own earlier stores, read past the L1 like the ring
-                    const float* src = c_first ? reinterpret_cast<const float*>(P.accum + a_idx) : reinterpret_cast<const float*>(sums_row);
-                    a.x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.y = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.z = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                have = true;
-            }
-            if (a_ok) {
-                const float* r = ring + (slot * ROW_PIXELS + lane) * 3u;
-                a.x += __hip_atomic_load(r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.y += __hip_atomic_load(r + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                a.z += __hip_atomic_load(r + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            job_rays += row_rays;
-            free_mask |= 1u << slot;
-            c_seq++;
-            c_first = false;
-            if (last) {  // the job is complete: its sums go to the accumulator, the next range of the tile may follow
-                if (a_ok) {
-                    float* dst = reinterpret_cast<float*>(P.accum + a_idx);  // alpha stays as it is
-                    __hip_atomic_store(dst, a.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1: write-through
-                    __hip_atomic_store(dst + 1, a.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(dst + 2, a.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (k + 1u < P.n_ranges) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every lane's texel stores have left the L2
-                    if (lane == 0) __hip_atomic_store(P.tile_done + tile, k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (P.tile_cost && lane == 0) atomicAdd(P.tile_cost + tile, (float)job_rays);
-                have = false;
-                c_first = true;
-                job_rays = 0;
-            }
-        }
-        if (have && a_ok) *sums_row = a;
-    };
     // One sample of a path has ended with `radiance`.
     auto finish_sample = [&](V3 radiance) {
         final_colour = final_colour + radiance;
         sample_i++;
         w.cur = LANE_NEXT;
         if (sample_i >= P.samples) {
-            V3 o = final_colour;
+            f4 o4;
+            o4.x = final_colour.x, o4.y = final_colour.y, o4.z = final_colour.z;
             if (P.samples != 1) {  // x / 1.0f == x: the common case needs no division
                 const float fs = (float)P.samples;
-                o.x = final_colour.x / fs;
-                o.y = final_colour.y / fs;
-                o.z = final_colour.z / fs;
+                o4.x = final_colour.x / fs;
+                o4.y = final_colour.y / fs;
+                o4.z = final_colour.z / fs;
             }
-            float* dst = ring + (tag & 0x7ffu) * 3u;
-            dst[0] = o.x, dst[1] = o.y, dst[2] = o.z;
-            // one pending path fewer in the row, its rays added
-            {
-                PT_LDS(uint32_t)* rec = reinterpret_cast<PT_LDS(uint32_t)*>(rows_lds + (tag >> 11) * 16u);
-                __hip_atomic_fetch_add(rec + 2, rays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(rec + 1, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            lane_rays += rays;
+            o4.w = 0.0f;
+            store_result(P, out_index, o4, rays, lane_rays);
             w.cur = LANE_IDLE;
         }
     };
@@ -443,23 +501,12 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         return go;
     };
 
-    bool gave_up = false;
+    uint64_t t_progress = __builtin_amdgcn_s_memrealtime();  // 100 MHz; when a path of this wave last ended
     for (uint32_t round = 0;; round++) {
-        // Watchdog: a scheduling bug must end the launch, not hang the GPU.
+        // Watchdog: a scheduling bug must end the launch, not hang the GPU.  It measures the time since a path
+        // of this wave last ended, so a long launch that makes progress never trips it.
         if ((round & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t_progress > P.watchdog_ticks) {
-            unsigned long long nth = 0;
-            if (lane == 0) nth = atomicAdd(&P.counters[10], 1ull);
-#ifdef PT_DEBUG_WATCHDOG
-            nth = __shfl(nth, 0);
-            if (nth < 6 && lane == 0) {
-                typedef uint32_t w2 __attribute__((ext_vector_type(2)));
-                const w2 rec = *reinterpret_cast<const PT_LDS(w2)*>(rows_lds + (c_seq & (MAX_RING_SLOTS - 1u)) * 16u);
-                printf("gaveup blk %u wave %u lane %u: i %u c %u free %x row_next %u f_issue %u exh %d stalled %d force %d cur %x tag %x rec %x %x\n",
-                       blockIdx.x, wave_in_block, lane, i_seq, c_seq, free_mask, row_next, f_issue, (int)exhausted, (int)stalled,
-                       (int)force, (uint32_t)w.cur, tag, rec.x, rec.y);
-            }
-#endif
-            gave_up = true;
+            if (lane == 0) atomicAdd(&P.counters[10], 1ull);
             break;
         }
         bool ran = false;
@@ -542,71 +589,59 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 }
             }
         }
-        // ---- restart: add the completed rows to the accumulator, close the paths that end at this hit / miss,
-        // hand the next pixel slots of the wave's tile to lanes without a path, start the next sample.  One step
-        // on purpose: every path needs these halves exactly once, and a separate state would only thin out the
-        // others.  Idle lanes of a wave whose ring is full do not ask for it (they wait for a row to complete),
-        // except in a forced round: the path that completed the oldest row may have ended in a scatter step
-        // (depth used up), after which nobody else would look at the ring again.
-        if (wants(lane_wants_restart(w.cur) && !(stalled && !force && w.cur == LANE_IDLE), PH_IDLE)) {
+        // ---- restart: close the paths that end at this hit / miss, hand consecutive path ids from the
+        // wave's chunk to lanes without a path, start the next sample.  One step on purpose: every
+        // path needs both halves exactly once, and a separate state would only thin out the others.
+        if (wants(lane_wants_restart(w.cur), PH_IDLE)) {
             ran = true;
-            stalled = false;
-            try_commit();
             if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
             if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
             unsigned long long m = __ballot(w.cur == LANE_IDLE);
             while (m) {
-                if (row_next == ROW_PIXELS) {  // open the next row
-                    if (f_issue == f_end && exhausted) break;
-                    if (i_seq - c_seq == P.ring_slots) {
-                        try_commit();  // rows may have completed in this very step
-                        if (i_seq - c_seq == P.ring_slots) {
-                            stalled = true;
-                            break;
+                if (next == end) {
+                    if (exhausted) break;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(P.work_counter, chunk);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // lane 0 is active here: the step is entered by the whole wave
+                    if (base >= P.total_units) {
+                        exhausted = true;
+                        break;
+                    }
+                    next = base * 64u;
+                    end = min(base + chunk, P.total_units) * 64u;
+                    {
+                        const uint32_t taken_to = base + chunk;
+                        chunk = guided_chunk_units(P.total_units, taken_to, P.inv_share, P.chunk_max);
+                        if (P.rank_chunk && taken_to < P.total_units) {
+                            // about where the queue will stand at this wave's next visit
+                            const uint32_t r = min(P.tiles_per_frame - 1u, (uint32_t)((float)taken_to * P.inv_n_frames));
+                            chunk = min(chunk, (uint32_t)P.rank_chunk[r]);
                         }
                     }
-                    if (f_issue == f_end) {  // the next job of the queue
-                        uint32_t job = 0;
-                        if (lane == 0) job = atomicAdd(P.work_counter, 1u);
-                        job = uniform(job);  // lane 0 is active here: the step is entered by the whole wave
-                        if (job >= P.n_tiles * P.n_ranges) {
-                            exhausted = true;
-                            break;
-                        }
-                        uint32_t k, rank, tx, ty;
-                        if (P.small_ids) divmod24(job, P.n_tiles, P.inv_n_tiles, k, rank);
-                        else k = job / P.n_tiles, rank = job - k * P.n_tiles;
-                        const uint32_t tile = uniform(P.tile_perm ? P.tile_perm[rank] : rank);
-                        if (P.small_ids) divmod24(tile, P.tiles_x, P.inv_tiles_x, ty, tx);
-                        else ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
-                        tile_xy = uniform(tx | (ty << 13));
-                        k_issue = uniform(k);
-                        f_issue = k_issue * P.job_frames;
-                        f_end = min(f_issue + P.job_frames, P.n_frames);
-                    }
-                    const uint32_t slot = (uint32_t)__builtin_ctz(free_mask);  // not empty: fewer rows live than slots
-                    free_mask &= free_mask - 1u;
-                    const uint32_t ri = i_seq & (MAX_RING_SLOTS - 1u);
-                    const uint32_t vx = min(8u, P.width - (tile_xy & 0x1fffu) * 8u), vy = min(8u, P.height - (tile_xy >> 13) * 8u);
-                    const uint32_t last = f_issue + 1u == f_end ? 0x80000000u : 0u;
-                    if (lane == 0) {
-                        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
-                        *reinterpret_cast<PT_LDS(w4)*>(rows_lds + ri * 16u) = w4{tile_xy | (slot << 26) | last, vx * vy, 0u, k_issue};
-                    }
-                    row_tag = (slot << 6) | (ri << 11);
-                    seed_cur = uniform(P.seeds[f_issue]);
-                    f_issue++;
-                    i_seq++;
-                    row_next = 0;
                 }
-                const uint32_t avail = ROW_PIXELS - row_next;
+                const uint32_t avail = end - next;
                 const uint32_t rank = lane_rank(m);
                 if (w.cur == LANE_IDLE && rank < avail) {
-                    const uint32_t slot = row_next + rank;
-                    const uint32_t px = (tile_xy & 0x1fffu) * 8u + (slot & 7u), py = (tile_xy >> 13) * 8u + (slot >> 3);
+                    const uint32_t pid = next + rank;
+                    const uint32_t unit = pid >> 6, slot = pid & 63u;
+                    uint32_t frame, tile, tx, ty;
+                    if (P.small_ids) {  // uniform: every id below 2^24, float-reciprocal division
+                        divmod24(unit, P.n_frames, P.inv_n_frames, tile, frame);
+                    } else {
+                        tile = unit / P.n_frames, frame = unit - tile * P.n_frames;
+                    }
+                    const uint32_t result_index = (frame * P.tiles_per_frame + tile) * 64u + slot;
+                    if (P.tile_perm) tile = P.tile_perm[tile];
+                    if (P.small_ids) {
+                        divmod24(tile, P.tiles_x, P.inv_tiles_x, ty, tx);
+                    } else {
+                        ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                    }
+                    const uint32_t px = tx * 8u + (slot & 7u), py = ty * 8u + (slot >> 3);
                     if (px < P.width && py < P.height) {
-                        ps.rng = pixel_seed(seed_cur, P.pixel_hash[py * P.width + px]);
-                        tag = row_tag | slot;
+                        const uint32_t pix = py * P.width + px;
+                        ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
+                        out_index = result_index;
                         pxy = px | (py << 16);
                         final_colour = mk(0.0f, 0.0f, 0.0f);
                         sample_i = 0;
@@ -614,10 +649,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         w.cur = LANE_NEXT;
                     }
                 }
-                row_next += min((uint32_t)__popcll(m), avail);
+                next += min((uint32_t)__popcll(m), avail);
                 m = __ballot(w.cur == LANE_IDLE);
             }
-            if (w.cur == LANE_IDLE && exhausted) w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
+            if (w.cur == LANE_IDLE) w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
             if (w.cur == LANE_NEXT) {
                 ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
                 ps.o = cam.pos;
@@ -635,17 +670,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         }
     }
 
-    // The rows that completed in the last restart step; rows of a range whose predecessor is still being added by
-    // another wave wait for it (that wave never waits for this one: it owns a job with a smaller number).
-    while (!gave_up) {
-        try_commit();
-        if (c_seq == i_seq) break;
-        __builtin_amdgcn_s_sleep(32);
-        if (__builtin_amdgcn_s_memrealtime() - t_progress > P.watchdog_ticks) {
-            if (lane == 0) atomicAdd(&P.counters[10], 1ull);
-            gave_up = true;
-        }
-    }
     flush_rays(P, lane_rays);
     if (COUNT) {
         unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
@@ -665,10 +689,72 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     }
 }
 
+
+// accum[p] += vec4(result[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side
+// (total, and per tile into `tile_cost` when given: the input of pt_tile_order_kernel).  Results lie in
+// [frame][tile rank][slot] order, ranks being those of the launch that produced them: one thread per
+// (tile rank, slot), i.e. one wave per tile; at any moment all waves stream through the same frame.
+// (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
+// measured 6x slower at 3840x2160.)
+__global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                  uint32_t tiles, uint32_t n_frames, const uint32_t* tile_perm,
+                                  unsigned long long* ray_total, float* tile_cost, uint32_t compact,
+                                  const unsigned long long* gave_up) {
+    // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
+    // so nothing of this launch is added.
+    if (*gave_up) return;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rank = gid >> 6, slot = gid & 63u;
+    unsigned long long rays = 0;
+    uint32_t tile = 0;
+    if (rank < tiles) {
+        tile = tile_perm ? tile_perm[rank] : rank;
+        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
+        if (px < width && py < height) {
+            const uint32_t i = py * width + px;
+            f4 a = accum[i];
+            const f4* src = results + (size_t)rank * 64u + slot;
+            const size_t frame_stride = (size_t)tiles * 64u;
+            if (compact) {  // 12-byte results; the path kernel has counted the rays
+                const float* c = reinterpret_cast<const float*>(results) + ((size_t)rank * 64u + slot) * 3u;
+                const size_t stride = frame_stride * 3u;
+                for (uint32_t f = 0; f < n_frames; f++) {
+                    const float* s = c + (size_t)f * stride;
+                    a.x += s[0];
+                    a.y += s[1];
+                    a.z += s[2];
+                    a.w += 0.0f;
+                }
+            } else {
+                for (uint32_t f = 0; f < n_frames; f++) {
+                    f4 s = src[(size_t)f * frame_stride];
+                    a.x += s.x;
+                    a.y += s.y;
+                    a.z += s.z;
+                    a.w += 0.0f;
+                    rays += (unsigned long long)s.w;
+                }
+            }
+            accum[i] = a;
+        }
+    }
+    rays = wave_sum(rays);
+    if ((threadIdx.x & 63u) == 0) {
+        // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
+        // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
+        if (rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+        if (tile_cost && rank < tiles) tile_cost[tile] = (float)rays;
+    }
+}
+
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
 // workgroup, a 256-bucket counting sort.  Ties land in arbitrary order, which nothing depends on.
 constexpr int ORDER_BLK = 1024;
-__global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm) {
+// rank_chunk[r]: units a chunk starting in the r-th tile of that order should hold so that it costs about
+// `chunk_rays` rays (the cost of one unit of a tile = its measured rays / frames_measured).
+__global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm,
+                                                                 uint16_t* rank_chunk, float frames_measured,
+                                                                 float chunk_rays, uint32_t chunk_max) {
     __shared__ uint32_t hist[256];
     __shared__ float red[ORDER_BLK];
     float mx = 0.0f;
@@ -693,7 +779,13 @@ __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* t
         }
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) perm[atomicAdd(&hist[bucket(tile_cost[t])], 1u)] = t;
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) {
+        const float c = tile_cost[t];
+        const uint32_t r = atomicAdd(&hist[bucket(c)], 1u);
+        perm[r] = t;
+        const float unit_rays = fmaxf(c / frames_measured, 1.0f);
+        rank_chunk[r] = (uint16_t)max(1u, min(chunk_max, (uint32_t)(chunk_rays / unit_rays)));
+    }
 }
 
 __global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
@@ -709,16 +801,16 @@ static long env_long(const char* name, long dflt) {
 }
 static void read_switches(Switches& s) {
     s.max_batch = (uint32_t)std::max(0l, env_long("MI355PT_MAX_BATCH", 0));
+    s.frame_buf_gb = (uint32_t)std::max(0l, env_long("MI355PT_FRAME_BUF_GB", 0));
     s.block = (uint32_t)env_long("MI355PT_BLOCK", 0);
     s.stack_lds = env_long("MI355PT_STACK_LDS", 6);
     s.node_cache_kb = env_long("MI355PT_NODE_CACHE_KB", -1);
     s.tile_order = env_long("MI355PT_TILE_ORDER", 1) != 0;
-    s.ring_slots = (uint32_t)std::min<long>(MAX_RING_SLOTS, std::max(1l, env_long("MI355PT_RING_SLOTS", MAX_RING_SLOTS)));
+    s.chunk = (uint32_t)std::min(1024l, std::max(0l, env_long("MI355PT_CHUNK", 0)));
+    if (const char* e = getenv("MI355PT_CHUNK_SHARE")) s.chunk_share = atof(e) > 0.0 ? (float)atof(e) : 2.0f;
+    if (const char* e = getenv("MI355PT_CHUNK_RAYS")) s.chunk_rays = std::max(64.0f, (float)atof(e));
+    if (const char* e = getenv("MI355PT_KERNEL")) s.lockstep = strcmp(e, "lockstep") == 0;
     s.watchdog_ms = (uint64_t)std::max(1l, env_long("MI355PT_WATCHDOG_MS", 20000));
-    s.job_frames_min = (uint32_t)std::max(1l, env_long("MI355PT_JOB_FRAMES_MIN", 4));
-    s.job_frames_max = (uint32_t)std::max<long>(s.job_frames_min, env_long("MI355PT_JOB_FRAMES_MAX", 32));
-    const uint32_t default_thr[6] = {12, 8, 24, 16, 6, 32};  // node, leaf, (unused), opaque, glass, restart
-    for (int k = 0; k < 6; k++) s.thr[k] = default_thr[k];
     if (const char* senv = getenv("MI355PT_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -778,10 +870,10 @@ void destroy(Device* d) {
     (void)hipFree(d->scene);
     (void)hipFree(d->accum);
     (void)hipFree(d->pixel_hash);
-    (void)hipFree(d->ring);
+    (void)hipFree(d->frame_buf);
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
-    (void)hipFree(d->tile_done);
+    (void)hipFree(d->rank_chunk);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
@@ -815,7 +907,6 @@ bool synchronize(Device* d, std::string& err) {
 #define PT_SYNC_ALL(d) PT_HIP(hipStreamSynchronize((d)->stream))
 
 static uint32_t stack_bytes(const SceneLayout& L, uint32_t block) { return std::max(1u, L.max_depth) * block * 4u; }
-static uint32_t rows_bytes(uint32_t block) { return (block / 64u) * ROWS_LDS_BYTES; }
 
 bool upload_scene(Device* d, const void* blob, const SceneLayout& layout, std::string& err) {
     DeviceGuard guard(d->id);
@@ -837,8 +928,7 @@ bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
     d->layout = layout;
     d->have_scene = true;
     d->perm_valid = false;
-    d->scene_in_lds = !layout.reference_walk &&
-                      lds_scene_bytes(layout) + stack_bytes(layout, 256) + rows_bytes(256) <= LDS_SCENE_LIMIT;
+    d->scene_in_lds = !layout.reference_walk && lds_scene_bytes(layout) + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
         d->have_scene = false;
@@ -859,8 +949,8 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     (void)hipFree(d->pixel_hash);
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
-    (void)hipFree(d->tile_done);
-    d->tile_done = nullptr;
+    (void)hipFree(d->rank_chunk);
+    d->rank_chunk = nullptr;
     d->accum = nullptr;
     d->pixel_hash = nullptr;
     d->tile_cost = nullptr, d->tile_perm = nullptr;
@@ -868,9 +958,9 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     const size_t n_tiles = (size_t)((width + 7) / 8) * ((height + 7) / 8);
     PT_HIP(hipMalloc(&d->accum, (size_t)n_pix * sizeof(f4)));
     PT_HIP(hipMalloc(&d->pixel_hash, (size_t)n_pix * sizeof(uint32_t)));
-    PT_HIP(hipMalloc(&d->tile_cost, ((n_tiles * sizeof(float)) + 15u) & ~(size_t)15u));
+    PT_HIP(hipMalloc(&d->tile_cost, n_tiles * sizeof(float)));
     PT_HIP(hipMalloc(&d->tile_perm, n_tiles * sizeof(uint32_t)));
-    PT_HIP(hipMalloc(&d->tile_done, ((n_tiles * sizeof(uint32_t)) + 15u) & ~(size_t)15u));
+    PT_HIP(hipMalloc(&d->rank_chunk, n_tiles * sizeof(uint16_t)));
     d->width = width, d->height = height, d->n_pix = n_pix;
     hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
                        height);
@@ -917,9 +1007,8 @@ bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err
 }
 
 template <int SCENE, bool COUNT, int BLK>
-static bool launch_render(Device* d, RenderParams& P, uint32_t lds_bytes, float* ring, size_t ring_cap_bytes,
-                          std::string& err) {
-    auto kern = pt_render_sched_kernel<SCENE, COUNT, BLK>;
+static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, bool lockstep, std::string& err) {
+    auto kern = lockstep ? pt_render_kernel<SCENE, COUNT, BLK> : pt_render_sched_kernel<SCENE, COUNT, BLK>;
     if (lds_bytes > 48u * 1024u)
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
@@ -927,36 +1016,31 @@ static bool launch_render(Device* d, RenderParams& P, uint32_t lds_bytes, float*
     PT_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, BLK, lds_bytes));
     if (per_cu < 1) per_cu = 1;
     uint32_t grid = (uint32_t)d->prop.multiProcessorCount * (uint32_t)per_cu;
-    // never launch more waves than there are jobs
-    const uint32_t max_blocks = (uint32_t)std::min<uint64_t>(0x7fffffffull, ((uint64_t)P.n_tiles * P.n_ranges + (BLK / 64) - 1u) / (BLK / 64));
+    // never launch more waves than there are 64-path units
+    uint32_t max_blocks = (P.total_units + (BLK / 64) - 1u) / (BLK / 64);
     grid = std::max(1u, std::min(grid, max_blocks));
-    // and never more than the ring holds
-    const size_t per_block = (size_t)(BLK / 64) * RING_WAVE_FLOATS * sizeof(float);
-    grid = (uint32_t)std::min<size_t>(grid, ring_cap_bytes / per_block);
-    if (grid == 0) {
-        err = "render: the result ring is too small for one workgroup";
-        return false;
-    }
-    P.ring = ring;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, P);
+    RenderParams Q = P;
+    const float share = d->sw.chunk_share;  // chunks are at most 1/share of an even split of what is left
+    Q.inv_share = 1.0f / (share * (float)grid * (float)(BLK / 64));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BLK), lds_bytes, d->stream, Q);
     PT_HIP(hipGetLastError());
     return true;
 }
 
 template <int BLK>
-static bool launch_render_blk(Device* d, RenderParams& P, uint32_t lds_bytes, int scene_mode, bool count, float* ring,
-                              size_t ring_cap_bytes, std::string& err) {
+static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_bytes, int scene_mode, bool count,
+                              bool lockstep, std::string& err) {
     if (scene_mode == SCENE_LDS_HALF)
-        return count ? launch_render<SCENE_LDS_HALF, true, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err)
-                     : launch_render<SCENE_LDS_HALF, false, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err);
+        return count ? launch_render<SCENE_LDS_HALF, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_LDS_HALF, false, BLK>(d, P, lds_bytes, lockstep, err);
     if (scene_mode == SCENE_LDS)
-        return count ? launch_render<SCENE_LDS, true, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err)
-                     : launch_render<SCENE_LDS, false, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err);
+        return count ? launch_render<SCENE_LDS, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_LDS, false, BLK>(d, P, lds_bytes, lockstep, err);
     if (scene_mode == SCENE_REFERENCE)
-        return count ? launch_render<SCENE_REFERENCE, true, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err)
-                     : launch_render<SCENE_REFERENCE, false, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err);
-    return count ? launch_render<SCENE_GLOBAL, true, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err)
-                 : launch_render<SCENE_GLOBAL, false, BLK>(d, P, lds_bytes, ring, ring_cap_bytes, err);
+        return count ? launch_render<SCENE_REFERENCE, true, BLK>(d, P, lds_bytes, lockstep, err)
+                     : launch_render<SCENE_REFERENCE, false, BLK>(d, P, lds_bytes, lockstep, err);
+    return count ? launch_render<SCENE_GLOBAL, true, BLK>(d, P, lds_bytes, lockstep, err)
+                 : launch_render<SCENE_GLOBAL, false, BLK>(d, P, lds_bytes, lockstep, err);
 }
 
 static hipEvent_t take_event(Device* d) {
@@ -995,7 +1079,7 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     for (auto& t : d->timed) {
         float ms = 0.0f;
         PT_HIP(hipEventElapsedTime(&ms, t.begin, t.end));
-        stats.render_ms += ms;
+        (t.resolve ? stats.resolve_ms : stats.render_ms) += ms;
     }
     unsigned long long host_counters[28];
     PT_HIP(hipMemcpy(host_counters, d->counters, sizeof host_counters, hipMemcpyDeviceToHost));
@@ -1013,10 +1097,11 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     stats.paths += d->pending_paths;
     stats.launches += d->pending_launches;
     if (host_counters[10]) {
-        // reported once: the rows the waves had completed are in the accumulator, the rest of the launch is missing
+        // Reported once.  The accumulation kernel skips a launch whose path kernel gave up (and every later one
+        // that was already queued), so the accumulator holds exactly the launches that completed before it.
         PT_HIP(hipMemset(d->counters + 10, 0, 8));
         err = "render: kernel watchdog expired (" + std::to_string(host_counters[10]) +
-              " waves gave up); the accumulator lacks part of the frames of that call";
+              " waves gave up); the frames of that launch and of the launches queued behind it were not added";
         return false;
     }
     return true;
@@ -1045,51 +1130,97 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         return true;
     }
     DeviceGuard guard(d->id);
+    const Switches& sw = d->sw;
 
     const uint32_t tiles_x = (d->width + 7) / 8, tiles_y = (d->height + 7) / 8;
     const uint32_t tiles = tiles_x * tiles_y;
-    // Frames per launch.  A launch ends with a tail in which the waves run out of tiles one after the other, so
-    // launches should be long; nothing but the seed buffer grows with the number of frames.
-    uint32_t batch = cfg.max_batch ? cfg.max_batch : d->sw.max_batch;
-    if (batch == 0) batch = 4096;
+    // Frames per launch.  The persistent kernel ends with a tail in which most waves have run out of
+    // work while a few finish their longest paths (about 1 ms at 1080p, whatever the launch size), so
+    // launches should be long: one launch covers as many frames as the frame buffer may hold --
+    // FRAME_BUF_DEFAULT_BYTES by default, at most a quarter of the free device memory, MI355PT_FRAME_BUF_GB
+    // overrides -- and 32-bit path ids allow.  Measured on MI355X, scene1 1080p, 256 frames: 4 launches
+    // 32.4 ms, 2 launches 30.3 ms, 1 launch 29.0 ms.
+    uint32_t batch = cfg.max_batch ? cfg.max_batch : sw.max_batch;
+    if (batch == 0) {
+        size_t budget = FRAME_BUF_DEFAULT_BYTES;
+        if (sw.frame_buf_gb) {
+            budget = (size_t)sw.frame_buf_gb << 30;
+        } else {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+                const size_t held = d->frame_cap * sizeof(f4);  // ours already
+                budget = std::min(budget, (free_b + held) / 4);
+            }
+        }
+        size_t by_mem = budget / ((size_t)tiles * 64u * sizeof(f4));
+        batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(by_mem, 4096));
+    }
+    batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
+    size_t need = (size_t)batch * tiles * 64u;  // whole tiles: [frame][tile rank][64 slots]
+    if (need > d->frame_cap) {
+        if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
+        (void)hipFree(d->frame_buf);
+        d->frame_buf = nullptr;
+        d->frame_cap = 0;
+        PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
+        d->frame_cap = need;
+    }
+    if (n_frames > d->seeds_cap) {
+        if (!finish(d, stats, err)) return false;
+        (void)hipFree(d->seeds);
+        d->seeds = nullptr;
+        d->seeds_cap = 0;
+        const size_t cap = std::max<size_t>(4096, 2 * (size_t)n_frames);
+        PT_HIP(hipMalloc(&d->seeds, cap * 4));
+        d->seeds_cap = cap;
+        d->seeds_head = 0;
+    }
+    if (d->seeds_head + n_frames > d->seeds_cap && !finish(d, stats, err)) return false;  // ring is full: drain
 
-    // ---- launch geometry
-    const Switches& sw = d->sw;
+    RenderParams P;
+    memset(&P, 0, sizeof P);
+    P.scene = d->scene;
+    P.L = d->layout;
+    P.cam = cam;
+    P.width = d->width, P.height = d->height, P.tiles_x = tiles_x, P.tiles_per_frame = tiles, P.n_pix = d->n_pix;
+    P.samples = cfg.samples, P.depth = cfg.depth;
+    P.pixel_hash = d->pixel_hash;
+    P.work_counter = d->work_counter;
+    P.counters = d->counters;
+    P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
+    const bool lockstep = sw.lockstep;
+    P.watchdog_ticks = sw.watchdog_ms * 100000ull;  // 100 MHz
+    P.inv_tiles_x = 1.0f / (float)tiles_x;
+    for (int k = 0; k < 6; k++) P.thr[k] = sw.thr[k];
+    P.chunk_max = sw.chunk ? sw.chunk : (d->scene_in_lds ? 32u : 4u);
+    // Short launches (fewer than about a hundred 64-path units per resident wave: below 32 frames at 1920x1080)
+    // are a few per cent faster with the smaller workgroups; long ones 7 % faster with 1024 lanes at 8 waves per SIMD.
+    const bool long_launch = (uint64_t)std::min(n_frames, batch) * tiles >= 96ull * 32ull * (uint64_t)d->prop.multiProcessorCount;
     const bool in_lds = d->scene_in_lds;
     const int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
                            : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
     const size_t lds_cu = 160u * 1024u;
-    const uint32_t cus = (uint32_t)d->prop.multiProcessorCount;
-    // Few jobs (small images, few frames): small workgroups, so that the waves spread over all compute units.
-    const bool few_tiles = (uint64_t)tiles * std::max(1u, batch / d->sw.job_frames_min) < cus * 24ull;
-    // Short launches (below 32 frames at 1920x1080) are a few per cent faster with the smaller workgroups; long
-    // ones 7 % faster with 1024 lanes at 8 waves per SIMD.
-    const bool long_launch = (uint64_t)batch * tiles >= 96ull * 32ull * (uint64_t)cus;
-    RenderParams P;
-    memset(&P, 0, sizeof P);
     uint32_t block, lds_bytes;
     if (in_lds) {
         P.scene_lds_bytes = lds_scene_bytes(d->layout);
-        // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks and the row
-        // tables are per lane / wave.  Larger workgroups amortise the copy (more waves fit next to it); deep trees
-        // make the stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
-        // Registers: the kernel needs about 70 vector registers (7 waves per SIMD: 28 per CU, 24 in whole
-        // 512-lane workgroups); its 1024-lane instance is compiled for 64 (8 per SIMD, two workgroups per CU) --
-        // more waves raise the instruction-issue ceiling the kernel runs at: scene1, 256 frames, 20.65 ms with
-        // 3 x 512 lanes per CU, 19.20 ms with 2 x 1024.
+        // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
+        // lane.  Larger workgroups amortise the copy (more waves fit next to it); deep trees make the
+        // stacks dominate and favour smaller ones.  Pick what keeps more waves resident per CU.
+        // Registers: the kernels need 70 vector registers (7 waves per SIMD: 28 per CU, 24 in whole 512-lane
+        // workgroups); the 1024-lane instance of the scheduled kernel is compiled for 64 (8 per SIMD, two
+        // workgroups per CU, one spilled register) -- more waves raise the instruction-issue ceiling the
+        // kernel runs at: scene1, 256 frames, 20.65 ms with 3 x 512 lanes per CU, 19.20 ms with 2 x 1024.
         auto waves_per_cu = [&](uint32_t blk) {
-            size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk) + rows_bytes(blk);
+            size_t per_block = (size_t)P.scene_lds_bytes + stack_bytes(d->layout, blk);
             size_t blocks = per_block ? lds_cu / per_block : 8;
             const size_t cap = blk == 1024 ? 32 : (blk == 512 ? 24 : 28);
             return std::min<size_t>(blocks * (blk / 64), cap);
         };
         block = waves_per_cu(512) > waves_per_cu(256) ? 512u : 256u;
-        if (long_launch && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
-        if (few_tiles) block = 256u;
+        if (!lockstep && long_launch && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
         if (sw.block == 256 || sw.block == 512 || sw.block == 1024) block = sw.block;
-        P.rows_lds_off = P.scene_lds_bytes + stack_bytes(d->layout, block);
-        lds_bytes = P.rows_lds_off + rows_bytes(block);
+        lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
     } else {
         // Scene in global memory.  LDS holds, per workgroup, the first stack entries of every lane and
         // as much of the top of the tree as still lets 24 waves stay resident on a CU.  Measured on
@@ -1097,24 +1228,22 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // 18.3 ms per 16 frames; everything in global memory 21.7 ms; a 64 KB prefix at 8 waves per CU
         // 33 ms (occupancy matters more than the size of the prefix).
         // MI355PT_STACK_LDS (entries) and MI355PT_NODE_CACHE_KB override the split (development).
-        block = !long_launch ? 512u : 1024u;  // the 1024-lane instance runs 8 waves per SIMD
-        if (few_tiles) block = 256u;
+        block = (lockstep || !long_launch) ? 512u : 1024u;  // the scheduled kernel's 1024-lane instance runs 8 waves per SIMD
         if (sw.block == 256 || sw.block == 512 || sw.block == 1024) block = sw.block;
         const uint32_t depth = std::max(1u, d->layout.max_depth);
         P.stack_lds_entries = (uint32_t)std::min<long>(depth, std::max<long>(1, sw.stack_lds));
         P.stack_spill_entries = std::max(1u, depth - P.stack_lds_entries);
         const uint32_t stack_lds = P.stack_lds_entries * block * 4u;
         const uint32_t blocks_per_cu = std::max(1u, (block == 1024u ? 32u : 24u) / (block / 64u));
-        const long budget = (long)(lds_cu / blocks_per_cu) - (long)stack_lds - (long)rows_bytes(block) - 2048;  // LDS is granted in granules
+        const long budget = (long)(lds_cu / blocks_per_cu) - (long)stack_lds - 2048;  // LDS is granted in granules
         long cache = sw.node_cache_kb >= 0 ? sw.node_cache_kb * 1024 : budget;
-        cache = std::min<long>(cache, (long)lds_cu - (long)stack_lds - (long)rows_bytes(block));
+        cache = std::min<long>(cache, (long)lds_cu - (long)stack_lds);
         cache = std::min<long>(cache, 4096l * (long)sizeof(Node64));  // the renumbered prefix (order_top_first)
         cache = std::min<long>(cache, (long)d->layout.n_nodes * (long)sizeof(Node64));
         cache = std::max<long>(cache, 0) / 64 * 64;
         P.scene_lds_bytes = (d->layout.off_nodes == 0) ? (uint32_t)cache : 0u;
-        P.rows_lds_off = P.scene_lds_bytes + stack_lds;
-        lds_bytes = P.rows_lds_off + rows_bytes(block);
-        const size_t need_spill = (size_t)cus * (2048u / block) * P.stack_spill_entries * block;
+        lds_bytes = P.scene_lds_bytes + stack_lds;
+        const size_t need_spill = (size_t)d->prop.multiProcessorCount * (2048u / block) * P.stack_spill_entries * block;
         if (need_spill > d->spill_cap) {
             if (!finish(d, stats, err)) return false;
             (void)hipFree(d->stack_spill);
@@ -1129,30 +1258,6 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         err = "render: traversal stacks do not fit in LDS (tree too deep)";
         return false;
     }
-    // The result ring: one per wave that can be resident.
-    P.ring_slots = sw.ring_slots;
-    {
-        const size_t need = (size_t)cus * 32u * RING_WAVE_FLOATS * sizeof(float);
-        if (need > d->ring_cap) {
-            if (!finish(d, stats, err)) return false;
-            (void)hipFree(d->ring);
-            d->ring = nullptr;
-            d->ring_cap = 0;
-            PT_HIP(hipMalloc(&d->ring, need));
-            d->ring_cap = need;
-        }
-    }
-    if (n_frames > d->seeds_cap) {
-        if (!finish(d, stats, err)) return false;
-        (void)hipFree(d->seeds);
-        d->seeds = nullptr;
-        d->seeds_cap = 0;
-        const size_t cap = std::max<size_t>(4096, 2 * (size_t)n_frames);
-        PT_HIP(hipMalloc(&d->seeds, cap * 4));
-        d->seeds_cap = cap;
-        d->seeds_head = 0;
-    }
-    if (d->seeds_head + n_frames > d->seeds_cap && !finish(d, stats, err)) return false;  // ring is full: drain
 
     // From here on work is queued: whatever fails, finish() has to run before the buffers are touched again.
     d->in_flight = true;
@@ -1162,73 +1267,65 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     PT_HIP(hipMemcpyAsync(dev_seeds, d->seed_staging.back().data(), (size_t)n_frames * 4, hipMemcpyHostToDevice,
                           d->stream));
 
-    P.scene = d->scene;
-    P.L = d->layout;
-    P.cam = cam;
-    P.width = d->width, P.height = d->height, P.tiles_x = tiles_x, P.n_tiles = tiles;
-    P.samples = cfg.samples, P.depth = cfg.depth;
-    P.pixel_hash = d->pixel_hash;
-    P.accum = d->accum;
-    P.work_counter = d->work_counter;
-    P.counters = d->counters;
-    P.ray_slots = d->ray_slots;
-    P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
-    P.watchdog_ticks = sw.watchdog_ms * 100000ull;  // 100 MHz
-    P.inv_tiles_x = 1.0f / (float)tiles_x;
-    P.inv_n_tiles = 1.0f / (float)tiles;
-    P.tile_done = d->tile_done;
-    for (int k = 0; k < 6; k++) P.thr[k] = sw.thr[k];
-
-    bool use_perm = sw.tile_order && d->perm_valid && memcmp(&cam, &d->perm_cam, sizeof cam) == 0 &&
+    // Rays a chunk should cost: a wave traces about 6.5 M rays/s, so 2 600 rays are 400 us per chunk and
+    // 6 144 waves issue 15 M queue atomics/s.  MI355PT_CHUNK_RAYS overrides (development switch).
+    const float chunk_rays = sw.chunk_rays;
+    const bool order_tiles = sw.tile_order;  // MI355PT_TILE_ORDER=0 keeps row-major tile order
+    bool use_perm = order_tiles && d->perm_valid && memcmp(&cam, &d->perm_cam, sizeof cam) == 0 &&
                     cfg.depth == d->perm_depth && cfg.samples == d->perm_samples;
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
-        const uint32_t nb = std::min(batch, n_frames - f0);
-        P.n_frames = nb;
-        // Frames per job: small enough that the queue holds several jobs per resident wave and ends with short
-        // ones, large enough that a job's texel traffic (one read, one write per job) stays small.
-        {
-            const uint64_t target_jobs = 8ull * cus * 32ull;
-            uint64_t jf = (uint64_t)nb * tiles / target_jobs;
-            jf = std::max<uint64_t>(sw.job_frames_min, std::min<uint64_t>(jf, sw.job_frames_max));
-            P.job_frames = (uint32_t)std::min<uint64_t>(jf, nb);
-            P.n_ranges = (nb + P.job_frames - 1u) / P.job_frames;
-            if ((uint64_t)P.n_ranges * tiles > 0xffffffffull) {
-                err = "render: too many jobs for one launch";
-                return false;
-            }
-            P.small_ids = (uint64_t)P.n_ranges * tiles < (1ull << 24) ? 1u : 0u;
-        }
-        if (P.n_ranges > 1) PT_HIP(hipMemsetAsync(d->tile_done, 0, (((size_t)tiles * 4u) + 15u) & ~(size_t)15u, d->stream));
-        P.tile_perm = use_perm ? d->tile_perm : nullptr;
-        P.seeds = dev_seeds + f0;
-        // The tile costs are measured on the first launch that is long enough to be representative after the
-        // camera or the settings changed, and again every 16th launch.
-        const bool measure = sw.tile_order && nb >= 8u && (!use_perm || d->since_measure >= 15u);
-        P.tile_cost = measure ? d->tile_cost : nullptr;
-        if (measure) PT_HIP(hipMemsetAsync(d->tile_cost, 0, (((size_t)tiles * 4u) + 15u) & ~(size_t)15u, d->stream));
-        PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
-        hipEvent_t ev_begin = take_event(d), ev_end = take_event(d);
-        bool ok = ev_begin && ev_end && hipEventRecord(ev_begin, d->stream) == hipSuccess;
-        if (ok) {
-            if (block == 512) ok = launch_render_blk<512>(d, P, lds_bytes, scene_mode, cfg.count, d->ring, d->ring_cap, err);
-            else if (block == 1024) ok = launch_render_blk<1024>(d, P, lds_bytes, scene_mode, cfg.count, d->ring, d->ring_cap, err);
-            else ok = launch_render_blk<256>(d, P, lds_bytes, scene_mode, cfg.count, d->ring, d->ring_cap, err);
-        } else {
-            err = "render: could not record a timing event";
-        }
-        if (ok && hipEventRecord(ev_end, d->stream) != hipSuccess) {
+    // one launch (path kernel or accumulation kernel) between two events; nothing is left half-recorded
+    auto timed_launch = [&](bool resolve, auto&& launch) -> bool {
+        hipEvent_t b = take_event(d), e = take_event(d);
+        bool ok = b && e && hipEventRecord(b, d->stream) == hipSuccess;
+        if (!ok) err = "render: could not record a timing event";
+        if (ok) ok = launch();
+        if (ok && hipEventRecord(e, d->stream) != hipSuccess) {
             ok = false;
             err = "render: could not record a timing event";
         }
-        if (!ok) {  // nothing is left half-recorded: the events go back to the pool
-            if (ev_begin) d->event_pool.push_back(ev_begin);
-            if (ev_end) d->event_pool.push_back(ev_end);
+        if (!ok) {
+            if (b) d->event_pool.push_back(b);
+            if (e) d->event_pool.push_back(e);
             return false;
         }
-        d->timed.push_back(Device::Timed{ev_begin, ev_end});
+        d->timed.push_back(Device::Timed{b, e, resolve});
+        return true;
+    };
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
+        const uint32_t nb = std::min(batch, n_frames - f0);
+        P.frame_out = d->frame_buf;
+        P.total_units = nb * tiles;
+        P.n_frames = nb;
+        P.inv_n_frames = 1.0f / (float)nb;
+        P.tile_perm = use_perm ? d->tile_perm : nullptr;
+        P.rank_chunk = use_perm ? d->rank_chunk : nullptr;
+        P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
+        P.seeds = dev_seeds + f0;
+        // The tile costs are measured on the first launch that is long enough to be representative after the
+        // camera or the settings changed, and again every 16th launch; measuring needs the ray count per path
+        // (16-byte results), all other launches write and re-read 12 bytes per path.
+        const bool measure = order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 15u);
+        P.compact = measure ? 0u : 1u;
+        P.ray_slots = d->ray_slots;
+        PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
+        if (!timed_launch(false, [&]() {
+                if (block == 512) return launch_render_blk<512>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
+                if (block == 1024) return launch_render_blk<1024>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
+                return launch_render_blk<256>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
+            }))
+            return false;
+        // accumulate in frame order (same stream: launches of one context never overlap)
+        if (!timed_launch(true, [&]() {
+                hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
+                                   d->frame_buf, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
+                                   measure ? d->tile_cost : nullptr, P.compact, d->counters + 10);
+                PT_HIP(hipGetLastError());
+                return true;
+            }))
+            return false;
         if (measure) {
             hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(ORDER_BLK), 0, d->stream, d->tile_cost, tiles,
-                               d->tile_perm);
+                               d->tile_perm, d->rank_chunk, (float)nb, chunk_rays, P.chunk_max);
             PT_HIP(hipGetLastError());
             d->perm_valid = true;
             d->perm_cam = cam;

@@ -3,7 +3,7 @@ sys.path.insert(0, os.getcwd())
 import pathtracer_amd as pa
 sc = pa.load_ron_scene("fixtures/scene1.ron")
 with pa.Renderer(sc, pa.Settings(1, 50), 1920, 1080, flags=pa.FLAG_COUNT) as r:
-    r.render(16); r.clear(); r.render(64)
+    r.render(16); r.clear(); r.render(int(os.environ.get("PH_F", 64)))
     s = r.stats()
     rays = s["rays"]
     print("rays", rays, "nodes/ray", s["nodes"]/rays, "tests/ray", s["tests"]/rays)
