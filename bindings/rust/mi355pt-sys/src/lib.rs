@@ -77,6 +77,7 @@ extern "C" {
     pub fn mi355pt_clear(ctx: *mut mi355pt_ctx) -> c_int;
     pub fn mi355pt_render(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
     pub fn mi355pt_render_async(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
+    pub fn mi355pt_render_static(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
     pub fn mi355pt_wait(ctx: *mut mi355pt_ctx) -> c_int;
     pub fn mi355pt_frames(ctx: *const mi355pt_ctx) -> i32;
     pub fn mi355pt_read_accum(ctx: *mut mi355pt_ctx, rgba: *mut f32, n_floats: usize) -> c_int;

@@ -131,6 +131,18 @@ int mi355pt_render(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
  * (offline.rs:50-52, main.rs:160-161); mi355pt_render() = mi355pt_render_async() + mi355pt_wait(). */
 int mi355pt_render_async(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
 int mi355pt_wait(mi355pt_ctx* ctx);
+/* mi355pt_render() for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): same frames, same bits, but the per-launch results, the seeds, the
+ * work-queue counter and the stack spill area live in a static 160 MiB device array of the library instead of
+ * buffers the context grows on demand, and the call makes no hipMalloc / hipFree / event creation.  No
+ * counterpart in the reference.  Limits (MI355PT_ERR_ARG with a message otherwise): at most 1024 frames per
+ * call; one frame of results (12 bytes per pixel of the image rounded up to 8x8 tiles) plus the scene's stack
+ * spill area must fit in the array -- 3840x2160 does, with any scene that fits beside it.  Launches are as long
+ * as the array allows (6 frames at 1920x1080), so this is slower than mi355pt_render(); it is not timed
+ * (render_ms / resolve_ms do not advance) and never re-measures the tile order.  Every device holds one copy of
+ * the array, shared by all contexts on that device, and its contents are overwritten by each call: two such
+ * calls that overlap on one device (from two contexts / threads) race.  Synchronous. */
+int mi355pt_render_static(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
 /* Renderer::samples (mod.rs:246-248): frames since the last clear, -1 before the first render
  * (queued frames count at once). */
 int32_t mi355pt_frames(const mi355pt_ctx* ctx);

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mi355pt_clear": (C.c_int, [C.c_void_p]),
     "mi355pt_render": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mi355pt_render_async": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "mi355pt_render_static": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mi355pt_wait": (C.c_int, [C.c_void_p]),
     "mi355pt_frames": (C.c_int32, [C.c_void_p]),
     "mi355pt_read_accum": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),

@@ -269,6 +269,38 @@ int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seed
     return MI355PT_OK;
 }
 
+int mi355pt_render_static(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+    if (!c) return MI355PT_ERR_ARG;
+    if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
+    if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
+    if (n_frames > gpu::STATIC_MAX_FRAMES)
+        return fail(c, MI355PT_ERR_ARG, "render_static: at most " + std::to_string(gpu::STATIC_MAX_FRAMES) + " frames per call");
+    SETTLE_OR_RETURN(c);
+    if (c->dirty) {  // mod.rs:169-195; the clear is a fill kernel and two memsets, no allocation
+        int r = mi355pt_clear(c);
+        if (r != MI355PT_OK) return r;
+    }
+    if (n_frames == 0) return MI355PT_OK;
+    uint32_t own[gpu::STATIC_MAX_FRAMES];
+    if (!seeds) {
+        for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
+        seeds = own;
+    }
+    gpu::RenderConfig cfg;
+    cfg.samples = c->settings.samples;
+    cfg.depth = c->settings.depth;
+    cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
+    cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
+    std::string err;
+    if (!gpu::render_static(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) {
+        const bool arg = err.rfind("render_static:", 0) == 0;  // a size the workspace cannot hold
+        return fail(c, arg ? MI355PT_ERR_ARG : MI355PT_ERR_DEVICE, err);
+    }
+    c->frames += (int32_t)n_frames;
+    c->seed_index += n_frames;
+    return MI355PT_OK;
+}
+
 int mi355pt_wait(mi355pt_ctx* c) {
     if (!c) return MI355PT_ERR_ARG;
     return settle(c);

@@ -50,6 +50,12 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
 bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
              RenderStats& stats, std::string& err);
 bool finish(Device* d, RenderStats& stats, std::string& err);
+// render() without any allocation: results, seeds, work-queue counter and stack spill area live in the
+// library's static workspace (one per device, shared by every context on it: calls that overlap on one
+// device race).  At most STATIC_MAX_FRAMES frames per call; fails when one frame of results does not fit.
+constexpr uint32_t STATIC_MAX_FRAMES = 1024;
+bool render_static(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+                   RenderStats& stats, std::string& err);
 bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
 void* accum_device_ptr(Device* d);

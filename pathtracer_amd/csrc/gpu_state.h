@@ -97,6 +97,21 @@ struct Device {
     uint32_t* work_counter = nullptr;  // [1]
     unsigned long long* counters = nullptr;  // [32] kernel counters, watchdog, step statistics
     unsigned long long* ray_slots = nullptr; // [RAY_SLOTS * RAY_SLOT_STRIDE] rays traced, striped
+    // This device's copy of the library's static workspace (render_static): its address on this device,
+    // looked up once when the first context on the device is created.
+    unsigned char* static_ws = nullptr;
+};
+
+// Device memory one render call works in beside the context's own buffers.  enqueue() grows the context's
+// buffers to what a call needs; render_static() describes a fixed area and nothing is ever allocated.
+struct Workspace {
+    void* frame_buf = nullptr;       // results of one launch
+    size_t frame_bytes = 0;
+    uint32_t* seeds = nullptr;       // one per frame of the call
+    int32_t* stack_spill = nullptr;
+    size_t spill_entries = 0;
+    uint32_t* work_counter = nullptr;
+    bool fixed = false;              // true: capacities are final, no timing events are created
 };
 
 #define PT_HIP(call)                                                                          \

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -818,6 +819,40 @@ static void read_switches(Switches& s) {
     }
 }
 
+// Static workspace of render_static(): callers that cannot allocate (code under graph capture, tight serving
+// loops, harnesses that forbid hipMalloc) render with the frame buffer, the seeds, the work-queue counter and
+// the stack spill area in this array instead of in buffers the context grows on demand.  Every device the
+// library runs on holds its own copy at its own address until the process ends.  In host code the array's
+// name is only a handle for hipGetSymbolAddress; kernels and memsets get the looked-up address.
+constexpr size_t STATIC_WS_BYTES = (size_t)160 << 20;
+constexpr size_t STATIC_WS_COUNTER = 0;        // work-queue counter
+constexpr size_t STATIC_WS_SEEDS = 256;        // STATIC_MAX_FRAMES seeds
+constexpr size_t STATIC_WS_DATA = 256 + (size_t)STATIC_MAX_FRAMES * 4;  // stack spill area, then results
+static_assert(STATIC_WS_DATA % 256 == 0, "sections of the static workspace are 256-byte aligned");
+static __device__ __align__(256) unsigned char scratch[STATIC_WS_BYTES];
+
+static std::mutex g_static_ws_mutex;
+static unsigned char* g_static_ws[64] = {nullptr};  // by device ordinal
+// Address of `scratch` on device `id` (which must be current), looked up once per device.
+static bool static_ws_address(int id, unsigned char** out, std::string& err) {
+    std::lock_guard<std::mutex> lock(g_static_ws_mutex);
+    if (id < 0 || id >= 64) {
+        *out = nullptr;  // render_static reports it
+        return true;
+    }
+    if (!g_static_ws[id]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            err = std::string("hipGetSymbolAddress(static workspace): ") + hipGetErrorString(e);
+            return false;
+        }
+        g_static_ws[id] = static_cast<unsigned char*>(p);
+    }
+    *out = g_static_ws[id];
+    return true;
+}
+
 bool create(int device_id, void* stream, Device** out, std::string& err) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
@@ -857,6 +892,10 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
     }
     (void)hipMemset(d->counters, 0, 256);
     (void)hipMemset(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8);
+    if (!static_ws_address(device_id, &d->static_ws, err)) {
+        destroy(d);
+        return false;
+    }
     *out = d;
     return true;
 }
@@ -1089,8 +1128,8 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     stats.accepted = host_counters[2];
     for (int k = 0; k < 5; k++) stats.bounces[k] = host_counters[3 + k];
     {
-        std::vector<unsigned long long> slots(RAY_SLOTS * RAY_SLOT_STRIDE);
-        PT_HIP(hipMemcpy(slots.data(), d->ray_slots, slots.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long slots[RAY_SLOTS * RAY_SLOT_STRIDE];
+        PT_HIP(hipMemcpy(slots, d->ray_slots, sizeof slots, hipMemcpyDeviceToHost));
         stats.rays = 0;
         for (uint32_t k = 0; k < RAY_SLOTS; k++) stats.rays += slots[(size_t)k * RAY_SLOT_STRIDE];
     }
@@ -1107,8 +1146,11 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     return true;
 }
 
-bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
-             RenderStats& stats, std::string& err) {
+// `fixed` == nullptr: the context's own buffers, grown to what the call needs.  Otherwise the call works in
+// the given area, allocates nothing (no device memory, no events: its launches are not timed) and fails
+// with a message when the area is too small.
+static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, const RenderConfig& cfg,
+                       const uint32_t* seeds, uint32_t n_frames, RenderStats& stats, std::string& err) {
     if (!d->have_scene) {
         err = "render: no scene";
         return false;
@@ -1141,7 +1183,9 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     // overrides -- and 32-bit path ids allow.  Measured on MI355X, scene1 1080p, 256 frames: 4 launches
     // 32.4 ms, 2 launches 30.3 ms, 1 launch 29.0 ms.
     uint32_t batch = cfg.max_batch ? cfg.max_batch : sw.max_batch;
-    if (batch == 0) {
+    if (fixed) {
+        batch = 0xffffffffu;  // bounded below by what the area holds, once the spill area is known
+    } else if (batch == 0) {
         size_t budget = FRAME_BUF_DEFAULT_BYTES;
         if (sw.frame_buf_gb) {
             budget = (size_t)sw.frame_buf_gb << 30;
@@ -1158,7 +1202,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
     size_t need = (size_t)batch * tiles * 64u;  // whole tiles: [frame][tile rank][64 slots]
-    if (need > d->frame_cap) {
+    if (!fixed && need > d->frame_cap) {
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
         (void)hipFree(d->frame_buf);
         d->frame_buf = nullptr;
@@ -1166,7 +1210,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
         d->frame_cap = need;
     }
-    if (n_frames > d->seeds_cap) {
+    if (!fixed && n_frames > d->seeds_cap) {
         if (!finish(d, stats, err)) return false;
         (void)hipFree(d->seeds);
         d->seeds = nullptr;
@@ -1176,7 +1220,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         d->seeds_cap = cap;
         d->seeds_head = 0;
     }
-    if (d->seeds_head + n_frames > d->seeds_cap && !finish(d, stats, err)) return false;  // ring is full: drain
+    if (!fixed && d->seeds_head + n_frames > d->seeds_cap && !finish(d, stats, err)) return false;  // ring is full: drain
 
     RenderParams P;
     memset(&P, 0, sizeof P);
@@ -1186,7 +1230,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     P.width = d->width, P.height = d->height, P.tiles_x = tiles_x, P.tiles_per_frame = tiles, P.n_pix = d->n_pix;
     P.samples = cfg.samples, P.depth = cfg.depth;
     P.pixel_hash = d->pixel_hash;
-    P.work_counter = d->work_counter;
+    P.work_counter = fixed ? fixed->work_counter : d->work_counter;
     P.counters = d->counters;
     P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
     const bool lockstep = sw.lockstep;
@@ -1202,6 +1246,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
                            : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
     const size_t lds_cu = 160u * 1024u;
     uint32_t block, lds_bytes;
+    size_t spill_in_use = 0;  // entries of the spill area this call's kernels address
     if (in_lds) {
         P.scene_lds_bytes = lds_scene_bytes(d->layout);
         // Workgroup size: the scene copy in LDS is shared by the workgroup, the traversal stacks are per
@@ -1244,7 +1289,15 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         P.scene_lds_bytes = (d->layout.off_nodes == 0) ? (uint32_t)cache : 0u;
         lds_bytes = P.scene_lds_bytes + stack_lds;
         const size_t need_spill = (size_t)d->prop.multiProcessorCount * (2048u / block) * P.stack_spill_entries * block;
-        if (need_spill > d->spill_cap) {
+        if (fixed) {
+            if (need_spill > fixed->spill_entries) {
+                err = "render_static: the traversal stacks of this scene need " + std::to_string(need_spill * 4) +
+                      " bytes of spill space, the static workspace has " + std::to_string(fixed->spill_entries * 4);
+                return false;
+            }
+            P.stack_spill = fixed->stack_spill;
+            spill_in_use = need_spill;
+        } else if (need_spill > d->spill_cap) {
             if (!finish(d, stats, err)) return false;
             (void)hipFree(d->stack_spill);
             d->stack_spill = nullptr;
@@ -1252,20 +1305,43 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
             PT_HIP(hipMalloc(&d->stack_spill, need_spill * sizeof(int32_t)));
             d->spill_cap = need_spill;
         }
-        P.stack_spill = d->stack_spill;
+        if (!fixed) P.stack_spill = d->stack_spill;
     }
     if (lds_bytes > lds_cu) {
         err = "render: traversal stacks do not fit in LDS (tree too deep)";
         return false;
     }
 
+    char* frame_buf = reinterpret_cast<char*>(d->frame_buf);
+    if (fixed) {
+        // what the area holds after the spill area: whole frames of 12-byte results (these launches never
+        // measure tile costs, so no result carries a ray count)
+        const size_t spill_bytes = (spill_in_use * 4u + 255u) & ~(size_t)255u;
+        const size_t per_frame = (size_t)tiles * 64u * 12u;
+        const size_t room = fixed->frame_bytes > spill_bytes ? fixed->frame_bytes - spill_bytes : 0;
+        if (room < per_frame) {
+            err = "render_static: one " + std::to_string(d->width) + "x" + std::to_string(d->height) + " frame needs " +
+                  std::to_string(per_frame) + " bytes of results, the static workspace has " + std::to_string(room);
+            return false;
+        }
+        frame_buf = static_cast<char*>(fixed->frame_buf) + spill_bytes;
+        batch = (uint32_t)std::min<size_t>({(size_t)batch, room / per_frame, (size_t)n_frames});
+    }
+
     // From here on work is queued: whatever fails, finish() has to run before the buffers are touched again.
     d->in_flight = true;
-    uint32_t* const dev_seeds = d->seeds + d->seeds_head;
-    d->seeds_head += n_frames;
-    d->seed_staging.emplace_back(seeds, seeds + n_frames);
-    PT_HIP(hipMemcpyAsync(dev_seeds, d->seed_staging.back().data(), (size_t)n_frames * 4, hipMemcpyHostToDevice,
-                          d->stream));
+    uint32_t* dev_seeds;
+    if (fixed) {
+        // the caller's array is read before this call returns (render_static waits), so it needs no host copy
+        dev_seeds = fixed->seeds;
+        PT_HIP(hipMemcpyAsync(dev_seeds, seeds, (size_t)n_frames * 4, hipMemcpyHostToDevice, d->stream));
+    } else {
+        dev_seeds = d->seeds + d->seeds_head;
+        d->seeds_head += n_frames;
+        d->seed_staging.emplace_back(seeds, seeds + n_frames);
+        PT_HIP(hipMemcpyAsync(dev_seeds, d->seed_staging.back().data(), (size_t)n_frames * 4, hipMemcpyHostToDevice,
+                              d->stream));
+    }
 
     // Rays a chunk should cost: a wave traces about 6.5 M rays/s, so 2 600 rays are 400 us per chunk and
     // 6 144 waves issue 15 M queue atomics/s.  MI355PT_CHUNK_RAYS overrides (development switch).
@@ -1275,6 +1351,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
                     cfg.depth == d->perm_depth && cfg.samples == d->perm_samples;
     // one launch (path kernel or accumulation kernel) between two events; nothing is left half-recorded
     auto timed_launch = [&](bool resolve, auto&& launch) -> bool {
+        if (fixed) return launch();
         hipEvent_t b = take_event(d), e = take_event(d);
         bool ok = b && e && hipEventRecord(b, d->stream) == hipSuccess;
         if (!ok) err = "render: could not record a timing event";
@@ -1293,7 +1370,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
     };
     for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
         const uint32_t nb = std::min(batch, n_frames - f0);
-        P.frame_out = d->frame_buf;
+        P.frame_out = reinterpret_cast<f4*>(frame_buf);
         P.total_units = nb * tiles;
         P.n_frames = nb;
         P.inv_n_frames = 1.0f / (float)nb;
@@ -1304,10 +1381,10 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // The tile costs are measured on the first launch that is long enough to be representative after the
         // camera or the settings changed, and again every 16th launch; measuring needs the ray count per path
         // (16-byte results), all other launches write and re-read 12 bytes per path.
-        const bool measure = order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 15u);
+        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 15u);
         P.compact = measure ? 0u : 1u;
         P.ray_slots = d->ray_slots;
-        PT_HIP(hipMemsetAsync(d->work_counter, 0, 4, d->stream));
+        PT_HIP(hipMemsetAsync(P.work_counter, 0, 4, d->stream));
         if (!timed_launch(false, [&]() {
                 if (block == 512) return launch_render_blk<512>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
                 if (block == 1024) return launch_render_blk<1024>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
@@ -1317,7 +1394,7 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         // accumulate in frame order (same stream: launches of one context never overlap)
         if (!timed_launch(true, [&]() {
                 hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
-                                   d->frame_buf, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
+                                   P.frame_out, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
                                    measure ? d->tile_cost : nullptr, P.compact, d->counters + 10);
                 PT_HIP(hipGetLastError());
                 return true;
@@ -1339,6 +1416,36 @@ bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint
         d->pending_paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * nb;
     }
     return true;
+}
+
+bool enqueue(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+             RenderStats& stats, std::string& err) {
+    return enqueue_in(d, nullptr, cam, cfg, seeds, n_frames, stats, err);
+}
+
+bool render_static(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
+                   RenderStats& stats, std::string& err) {
+    if (!finish(d, stats, err)) return false;  // queued work first: it may still use the context's buffers
+    if (!d->static_ws) {
+        err = "render_static: no static workspace on this device (device ordinal above 63)";
+        return false;
+    }
+    if (n_frames > STATIC_MAX_FRAMES) {
+        err = "render_static: at most " + std::to_string(STATIC_MAX_FRAMES) + " frames per call";
+        return false;
+    }
+    Workspace ws;
+    ws.fixed = true;
+    ws.work_counter = reinterpret_cast<uint32_t*>(d->static_ws + STATIC_WS_COUNTER);
+    ws.seeds = reinterpret_cast<uint32_t*>(d->static_ws + STATIC_WS_SEEDS);
+    ws.stack_spill = reinterpret_cast<int32_t*>(d->static_ws + STATIC_WS_DATA);
+    ws.spill_entries = (STATIC_WS_BYTES - STATIC_WS_DATA) / 4u;
+    ws.frame_buf = d->static_ws + STATIC_WS_DATA;  // enqueue_in places the results behind the spill area in use
+    ws.frame_bytes = STATIC_WS_BYTES - STATIC_WS_DATA;
+    const bool queued = enqueue_in(d, &ws, cam, cfg, seeds, n_frames, stats, err);
+    std::string err2;
+    const bool done = finish(d, stats, queued ? err : err2);  // waits: the area and `seeds` are free again on return
+    return queued && done;
 }
 
 }  // namespace gpu

@@ -254,6 +254,16 @@ class Renderer:
         fn = lib().mi355pt_render if wait else lib().mi355pt_render_async
         self._check(fn(self._ctx, int(n_frames), p))
 
+    def render_static(self, n_frames=1, seeds=None):
+        """mi355pt_render_static: the same frames without any device allocation (static workspace)."""
+        if seeds is not None:
+            seeds = np.ascontiguousarray(seeds, np.uint32)
+            n_frames = len(seeds)
+            p = seeds.ctypes.data_as(C.POINTER(C.c_uint32))
+        else:
+            p = None
+        self._check(lib().mi355pt_render_static(self._ctx, int(n_frames), p))
+
     def wait(self):
         self._check(lib().mi355pt_wait(self._ctx))
 
