@@ -450,6 +450,31 @@ def test_converged_image_matches_reference_png(pa):
     assert rmse <= 3.0
 
 
+def test_oracle_image_of_the_reference_setup_byte_for_byte(pa):
+    # One chain on one input: tests/golden/mdimg_oracle_1000.png is the ORACLE's rgb8 image of the reference's
+    # offline set-up (scene1, 1280x720, 1000 frames, default seed schedule; made by make_mdimg_check.py, which
+    # also records its RMSE of 0.79 / 255 against the reference's own mdimg.png).  The GPU path, through the C ABI
+    # incl. mi355pt_to_rgb8, must give those bytes exactly.
+    import json
+    from PIL import Image
+    gold = np.asarray(Image.open(os.path.join(GOLDEN, "mdimg_oracle_1000.png")).convert("RGB"))
+    with open(os.path.join(GOLDEN, "mdimg_check.json")) as f:
+        meta = json.load(f)
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    with pa.Renderer(sc, pa.Settings(1, 50), meta["width"], meta["height"], base_seed=meta["base_seed"]) as r:
+        r.render(meta["frames"])
+        img = r.to_rgb8()
+        assert r.stats()["rays"] == meta["readings"]["always_draws"]["rays"]
+    assert img.shape == gold.shape and np.array_equal(img, gold)
+    with pa.Renderer(sc, pa.Settings(1, 50), meta["width"], meta["height"], base_seed=meta["base_seed"],
+                     flags=pa.FLAG_GLASS_SHORT_CIRCUIT) as r:
+        r.render(meta["frames"])
+        assert r.stats()["rays"] == meta["readings"]["short_circuit"]["rays"]
+        other = r.to_rgb8()
+    # the other reading of compute.wgsl:344 is a different image (631 pixels), equally far from mdimg.png
+    assert int(np.count_nonzero((other != gold).any(axis=2))) == meta["between_readings"]["pixels_differing"]
+
+
 def test_accumulator_is_visible_to_torch_without_a_copy(pa):
     # the multi-GPU path hands the library's accumulator to torch.distributed; run it the way
     # bench.py does (torch first, then the library) in a fresh process

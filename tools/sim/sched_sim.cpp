@@ -278,6 +278,138 @@ static void run_pool(const std::vector<Path>& paths, size_t first, size_t last, 
     }
 }
 
+// ---- policy D: a workgroup of `G` waves that exchange paths waiting for a scatter step through shared
+// pools (one per scatter class).  A wave whose population of a class is below its run threshold deposits
+// those lanes (they become idle at once and are refilled by the next restart); a restart step first
+// withdraws from a pool that holds at least `wmin` paths and runs that scatter with the lanes it got.
+// Waves advance on their own clocks (instruction slots); the next wave to act is the one furthest behind.
+struct GroupCfg {
+    int waves = 16;
+    int thr[5] = {12, 8, 16, 6, 32};  // node, leaf, opaque run, glass run, restart
+    int dep_max[2] = {64, 64};        // deposit only populations below this (and below the run threshold)
+    int wmin[2] = {32, 16};           // pool size from which a restart withdraws
+    int cap[2] = {128, 128};
+};
+static void run_group(const std::vector<Path>& paths, size_t first, size_t last, const GroupCfg& cfg, Tally& tl,
+                      double* max_pool) {
+    struct Wave {
+        Lane ln[64];
+        double clock = 0;
+        bool force = false, done = false;
+    };
+    std::vector<Wave> wv(cfg.waves);
+    std::deque<Parked> pool[2];
+    size_t next = first;
+    auto step = [&](Wave& w, int kind, int n) { tl.add(kind, n), w.clock += cost[kind]; };
+    for (;;) {
+        Wave* wp = nullptr;
+        for (auto& w : wv) if (!w.done && (!wp || w.clock < wp->clock)) wp = &w;
+        if (!wp) break;
+        Wave& w = *wp;
+        auto count = [&](char c) { int n = 0; for (auto& l : w.ln) n += l.st == c; return n; };
+        auto advance_walk = [&](Lane& l) {
+            l.pos++;
+            l.st = next_state(paths[l.path], l.seg, l.pos);
+            if (l.st == 'F') l.st = paths[l.path][l.seg].cls;
+        };
+        auto scatter_lane = [&](Lane& l) {
+            const Segment& sg = paths[l.path][l.seg];
+            if (sg.ends) l.st = 'I', l.path = -1;
+            else l.seg++, l.pos = 0, l.st = next_state(paths[l.path], l.seg, 0);
+        };
+        bool ran = false;
+        int n = count('N');
+        if (n >= cfg.thr[0] || (w.force && n)) {
+            ran = true;
+            for (;;) {
+                step(w, K_NODE, n);
+                for (auto& l : w.ln) if (l.st == 'N') advance_walk(l);
+                n = count('N');
+                if (n < cfg.thr[0]) break;
+            }
+        }
+        n = count('L');
+        if (n >= cfg.thr[1] || (w.force && n)) {
+            ran = true;
+            for (;;) {
+                step(w, K_LEAF, n);
+                for (auto& l : w.ln) if (l.st == 'L') advance_walk(l);
+                n = count('L');
+                if (n < cfg.thr[1]) break;
+            }
+        }
+        for (int c = 0; c < 2; c++) {
+            const char ch = c == 0 ? 'O' : 'G';
+            const int kind = c == 0 ? K_OPAQUE : K_GLASS;
+            int m = count(ch);
+            if (!m) continue;
+            if (m >= cfg.thr[2 + c] || (w.force && (int)pool[c].size() + m > cfg.cap[c])) {
+                ran = true;
+                step(w, kind, m);
+                for (auto& l : w.ln) if (l.st == ch) scatter_lane(l);
+            } else if (m < cfg.dep_max[c] && (int)pool[c].size() + m <= cfg.cap[c]) {
+                ran = true;
+                step(w, K_RETIRE, m);
+                for (auto& l : w.ln) if (l.st == ch) pool[c].push_back({l.path, l.seg}), l.st = 'I', l.path = -1;
+            } else if (w.force) {
+                ran = true;
+                step(w, kind, m);
+                for (auto& l : w.ln) if (l.st == ch) scatter_lane(l);
+            }
+        }
+        n = count('I') + count('T');
+        const bool queue_empty = next >= last;
+        if (n >= cfg.thr[4] || (w.force && n) || (queue_empty && n && (pool[0].size() || pool[1].size()))) {
+            bool did = false;
+            int terminal = count('T');
+            for (auto& l : w.ln) if (l.st == 'T') l.st = 'I', l.path = -1;
+            // withdraw: the fuller pool first
+            for (int pass = 0; pass < 2; pass++) {
+                const int c = (pool[0].size() >= pool[1].size()) == (pass == 0) ? 0 : 1;
+                const int idle = count('I');
+                const int have = (int)pool[c].size();
+                if (!idle || !have) continue;
+                if (have < cfg.wmin[c] && !queue_empty && !w.force) continue;
+                const int take = std::min(idle, have);
+                const char ch = c == 0 ? 'O' : 'G';
+                int got = 0;
+                for (auto& l : w.ln) if (l.st == 'I' && got < take) {
+                    Parked p = pool[c].front(); pool[c].pop_front();
+                    l.path = p.path, l.seg = p.seg, l.st = ch, got++;
+                }
+                step(w, K_REFILL, got);
+                const int m = count(ch);  // with whatever the wave still held of that class
+                step(w, c == 0 ? K_OPAQUE : K_GLASS, m);
+                for (auto& l : w.ln) if (l.st == ch) scatter_lane(l);
+                did = true;
+            }
+            const int idle = count('I');
+            if (idle && (!queue_empty || terminal || !did)) {
+                int started = 0;
+                for (auto& l : w.ln) if (l.st == 'I') {
+                    if (next < last) l.path = (int)next++, l.seg = 0, l.pos = 0, l.st = next_state(paths[l.path], 0, 0), started++;
+                    else if (pool[0].empty() && pool[1].empty()) l.st = 'X';
+                }
+                if (started || terminal) step(w, K_RESTART, std::max(started, terminal)), did = true;
+            }
+            ran = ran || did;
+        }
+        *max_pool = std::max(*max_pool, (double)(pool[0].size() + pool[1].size()));
+        if (!ran) {
+            if (count('X') == 64) { w.done = true; continue; }
+            bool all_idle = true;
+            for (auto& l : w.ln) all_idle = all_idle && (l.st == 'I' || l.st == 'X');
+            if (all_idle && queue_empty && pool[0].empty() && pool[1].empty()) {
+                for (auto& l : w.ln) l.st = 'X';
+                w.done = true;
+                continue;
+            }
+            if (w.force) w.clock += 10;  // nothing to do yet: wait for the others
+            w.force = true;
+        } else w.force = false;
+    }
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) return 1;
     Scene sc;
@@ -433,6 +565,40 @@ int main(int argc, char** argv) {
                 char nm[96];
                 snprintf(nm, sizeof nm, "pool cap %3d thr %d,%d,%d,%d,%d,%d,%d", cap, th[0], th[1], th[2], th[3], th[4], th[5], th[6]);
                 report(nm, tl, mp);
+            }
+    }
+    if (!quick) {
+        const size_t per_group = 16 * per_wave;
+        auto run_cfg = [&](const GroupCfg& g, const char* tag) {
+            Tally tl;
+            double mp = 0;
+            for (size_t f = 0; f < paths.size(); f += per_group) run_group(paths, f, std::min(paths.size(), f + per_group), g, tl, &mp);
+            char nm[128];
+            snprintf(nm, sizeof nm, "group%s thr %d,%d,%d,%d,%d dep<%d,%d wmin %d,%d cap %d", tag, g.thr[0], g.thr[1], g.thr[2], g.thr[3],
+                     g.thr[4], g.dep_max[0], g.dep_max[1], g.wmin[0], g.wmin[1], g.cap[0]);
+            report(nm, tl, mp);
+            return tl.total();
+        };
+        {
+            GroupCfg base;  // deposits disabled: 16 independent waves sharing one queue
+            base.dep_max[0] = base.dep_max[1] = 0;
+            run_cfg(base, " (no exchange)");
+        }
+        double best = 1e30;
+        if (const char* e = getenv("SIM_XCOST")) cost[K_RETIRE] *= atof(e), cost[K_REFILL] *= atof(e);
+        const int cap_env = getenv("SIM_CAP") ? atoi(getenv("SIM_CAP")) : 128;
+        for (int nthr : {12, 16}) for (int lthr : {8}) for (int othr : {32, 65}) for (int gthr : {65})
+            for (int rthr : {24, 32}) for (int wo : {32, 48, 64}) for (int wg : {16, 32, 64}) for (int cap : {cap_env}) {
+                GroupCfg g;
+                g.thr[0] = nthr, g.thr[1] = lthr, g.thr[2] = othr, g.thr[3] = gthr, g.thr[4] = rthr;
+                g.wmin[0] = std::min(wo, cap), g.wmin[1] = std::min(wg, cap), g.cap[0] = g.cap[1] = cap;
+                Tally tl;
+                double mp = 0;
+                for (size_t f = 0; f < paths.size(); f += per_group) run_group(paths, f, std::min(paths.size(), f + per_group), g, tl, &mp);
+                if (tl.total() < best) {
+                    best = tl.total();
+                    run_cfg(g, "");
+                }
             }
     }
     {   // every step at 64 lanes: the floor of any policy
