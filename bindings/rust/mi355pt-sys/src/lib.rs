@@ -54,6 +54,8 @@ pub struct mi355pt_stats {
     pub scene_bytes: u32,
     pub scene_in_lds: u32,
     pub node_format: u32,
+    pub exchange_on: u32,
+    pub exchange: [u64; 4],
 }
 
 extern "C" {

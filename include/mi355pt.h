@@ -83,6 +83,9 @@ typedef struct mi355pt_stats {
     uint32_t scene_in_lds; /* 1 when the blob is staged in LDS by every workgroup (small scenes; 0 under
                               MI355PT_BVH_REFERENCE / mi355pt_set_bvh, whose walk reads global memory) */
     uint32_t node_format;  /* 0: 64-byte nodes, float boxes; 1: 32-byte nodes, binary16 boxes (LDS scenes only) */
+    uint32_t exchange_on;  /* 1 when the last launch ran the kernel variant that exchanges waiting paths between waves */
+    uint64_t exchange[4];  /* that variant: pool deposits, lanes deposited, withdrawals, lanes withdrawn
+                              (MI355PT_FLAG_COUNT only) */
 } mi355pt_stats;
 
 /* ---- context: Renderer::new / drop (mod.rs:106-146) ---------------------------------------- */

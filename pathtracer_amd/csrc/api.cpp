@@ -368,6 +368,8 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
     out->scene_bytes = c->layout.total_bytes;
     out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
     out->node_format = c->have_scene ? c->layout.node_half : 0u;
+    out->exchange_on = c->stats.exchange_on ? 1u : 0u;
+    for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
     return MI355PT_OK;
 }
 

@@ -23,6 +23,8 @@ struct RenderStats {
     double render_ms = 0.0;  // device time of the path kernels (HIP events on the render stream)
     double resolve_ms = 0.0; // device time of the frame-order accumulation kernels
     uint32_t launches = 0;
+    uint64_t exchange[4] = {0, 0, 0, 0};  // exchange variant: deposits, lanes deposited, withdrawals, lanes withdrawn [counting only]
+    bool exchange_on = false;             // the last launch ran the exchange variant
 };
 
 struct RenderConfig {

@@ -45,6 +45,10 @@ struct Switches {
     bool lockstep = false;      // MI355PT_KERNEL=lockstep: the simple kernel
     uint64_t watchdog_ms = 20000;  // MI355PT_WATCHDOG_MS
     uint32_t thr[6] = {12, 8, 24, 16, 6, 32};  // MI355PT_SCHED: step thresholds node, leaf, -, opaque, glass, restart
+    bool exchange = false;                      // MI355PT_XCHG=1: exchange variant of the scheduled kernel
+    uint32_t pool_min[2] = {48, 32};            // MI355PT_XCHG_MIN: pool sizes from which a restart withdraws
+    uint32_t pool_dep_min[2] = {4, 2};          // MI355PT_XCHG_DEP_MIN: fewest waiting lanes worth a deposit
+    uint32_t xthr[6] = {12, 8, 24, 16, 6, 32}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
 };
 // Results of one launch wait in a frame buffer for the accumulation kernel; it is at most this large (and at
 // most a quarter of the free device memory): 334 frames at 1920x1080, 84 at 3840x2160.

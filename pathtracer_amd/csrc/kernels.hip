@@ -181,7 +181,17 @@ struct RenderParams {
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
     int32_t* stack_spill;
     uint32_t stack_lds_entries, stack_spill_entries;
+    // Exchange variant of pt_render_sched_kernel: LDS offset of the workgroup's two path pools and the pool
+    // size from which a restarting wave withdraws (opaque, glass)
+    uint32_t pool_off;
+    uint32_t pool_min[2];
+    uint32_t pool_dep_min[2];  // fewest waiting lanes worth a deposit
 };
+
+// Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
+// a stack of POOL_CAP records of 16 words, stored as four planes of 16-byte quarters so that consecutive slots
+// hit consecutive banks.  Header: per class a lock word and the entry count.
+constexpr uint32_t POOL_CAP = 64, POOL_HEADER = 64, POOL_BYTES = POOL_HEADER + 2u * POOL_CAP * 64u;
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,11 +438,14 @@ __device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32
 #endif
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
-template <int SCENE, bool COUNT, int BLK>
+template <int SCENE, bool COUNT, int BLK, bool XCHG = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 1024 ? 8 : 1, 8))) pt_render_sched_kernel(const RenderParams P) {
     constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(PT_LDS(char)*)smem;
+    if constexpr (XCHG) {  // empty pools, locks open (stage_scene ends with the barrier)
+        if (threadIdx.x < POOL_HEADER / 4u) *reinterpret_cast<PT_LDS(uint32_t)*>(lds0 + P.pool_off + threadIdx.x * 4u) = 0u;
+    }
     stage_scene<SCENE, BLK>(P, lds0);
     using Mem = typename SceneMem<SCENE>::type;
     using Stack = typename std::conditional<LDS_SCENE, LdsStack<BLK>, SpillStack<BLK>>::type;
@@ -502,6 +515,105 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         return go;
     };
 
+    // ---- exchange of waiting paths between the waves of the workgroup (XCHG).  A lane whose walk has ended
+    // holds nothing but its path: ray, throughput, generator, bounce count, the hit, where its result goes.
+    // A wave that has too few lanes waiting for a scatter class to run it parks those paths in the class's pool
+    // and frees the lanes; a wave that restarts takes a batch out of a well-filled pool into its idle lanes and
+    // runs that scatter with many lanes at once.  One lock per pool, held by lane 0 across the copy.
+    uint32_t x_dep = 0, x_dep_lanes = 0, x_wd = 0, x_wd_lanes = 0;
+    [[maybe_unused]] const uint32_t pool = lds0 + P.pool_off;
+    auto pool_word = [&](uint32_t off) { return reinterpret_cast<PT_LDS(uint32_t)*>(pool + off); };
+    auto pool_lock = [&](uint32_t cls) {  // lane 0 only; the holder never waits for anything, so this ends
+        uint32_t expected = 0u, spins = 0u;
+        while (!__hip_atomic_compare_exchange_strong(pool_word(cls * 8u), &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_WORKGROUP)) {
+            expected = 0u;
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 22)) {  // a bug must end the launch, not hang the GPU: flag it like the watchdog does
+                atomicAdd(&P.counters[10], 1ull);
+                break;
+            }
+        }
+    };
+    auto pool_unlock = [&](uint32_t cls) {
+        __hip_atomic_store(pool_word(cls * 8u), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto pool_count = [&](uint32_t cls) -> uint32_t {
+        const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+    };
+    typedef uint32_t xw4 __attribute__((ext_vector_type(4)));
+    // Parks the paths of the lanes with `mine` (all in scatter class `cls`); false when the pool has no room.
+    auto deposit = [&](uint32_t cls, bool mine) -> bool {
+        const unsigned long long m = __ballot(mine);
+        const uint32_t n = (uint32_t)__popcll(m);
+        uint32_t base = 0xffffffffu;
+        if (lane == 0) {
+            pool_lock(cls);
+            const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (c + n <= POOL_CAP) base = c;
+            else pool_unlock(cls);
+        }
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base == 0xffffffffu) return false;
+        if (mine) {
+            // one word per store, straight from the registers the values live in (16-byte stores would need them
+            // copied into aligned register quads first: vector instructions, the scarce kind here)
+            const uint32_t a = pool + POOL_HEADER + cls * (POOL_CAP * 64u) + (base + lane_rank(m)) * 4u;
+            auto put = [&](uint32_t k, uint32_t v) { *reinterpret_cast<PT_LDS(uint32_t)*>(a + k * (POOL_CAP * 4u)) = v; };
+            put(0, __float_as_uint(ps.o.x)), put(1, __float_as_uint(ps.o.y)), put(2, __float_as_uint(ps.o.z));
+            put(3, __float_as_uint(ps.d.x)), put(4, __float_as_uint(ps.d.y)), put(5, __float_as_uint(ps.d.z));
+            put(6, __float_as_uint(ps.colour.x)), put(7, __float_as_uint(ps.colour.y)), put(8, __float_as_uint(ps.colour.z));
+            put(9, ps.rng), put(10, (uint32_t)ps.bounce), put(11, __float_as_uint(w.best_t));
+            put(12, (uint32_t)w.best_code), put(13, mbits), put(14, out_index), put(15, rays);
+            w.cur = LANE_IDLE;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's record is written before the count says so
+        if (lane == 0) {
+            __hip_atomic_store(pool_word(cls * 8u + 4u), base + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pool_unlock(cls);
+        }
+        if (COUNT) x_dep++, x_dep_lanes += n;
+        return true;
+    };
+    // Takes up to one path per lane with `free_lane` out of pool `cls` when it holds at least `wmin`; the lanes
+    // that got one are in that class's scatter state afterwards.  Returns whether anything was taken.
+    auto withdraw = [&](uint32_t cls, bool free_lane, uint32_t wmin) -> bool {
+        if (pool_count(cls) < wmin) return false;  // a look without the lock
+        const unsigned long long m = __ballot(free_lane);
+        const uint32_t k = (uint32_t)__popcll(m);
+        if (k == 0u) return false;
+        uint32_t base = 0u, take = 0u;
+        if (lane == 0) {
+            pool_lock(cls);
+            const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            take = c >= wmin ? min(c, k) : 0u;
+            base = c - take;
+            if (take) __hip_atomic_store(pool_word(cls * 8u + 4u), base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else pool_unlock(cls);
+        }
+        take = (uint32_t)__builtin_amdgcn_readfirstlane((int)take);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (take == 0u) return false;
+        const uint32_t rank = lane_rank(m);
+        if (free_lane && rank < take) {
+            const uint32_t a = pool + POOL_HEADER + cls * (POOL_CAP * 64u) + (base + rank) * 4u;
+            auto get = [&](uint32_t k) { return *reinterpret_cast<const PT_LDS(uint32_t)*>(a + k * (POOL_CAP * 4u)); };
+            ps.o = mk(__uint_as_float(get(0)), __uint_as_float(get(1)), __uint_as_float(get(2)));
+            ps.d = mk(__uint_as_float(get(3)), __uint_as_float(get(4)), __uint_as_float(get(5)));
+            ps.colour = mk(__uint_as_float(get(6)), __uint_as_float(get(7)), __uint_as_float(get(8)));
+            ps.rng = get(9), ps.bounce = (int32_t)get(10);
+            w.best_t = __uint_as_float(get(11)), w.best_code = (int32_t)get(12);
+            mbits = get(13), out_index = get(14), rays = get(15);
+            final_colour = mk(0.0f, 0.0f, 0.0f), sample_i = 0;  // one sample per path in this variant
+            w.cur = cls ? LANE_GLASS : LANE_OPAQUE;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane has its record before the slots are free again
+        if (lane == 0) pool_unlock(cls);
+        if (COUNT) x_wd++, x_wd_lanes += take;
+        return true;
+    };
+
     uint64_t t_progress = __builtin_amdgcn_s_memrealtime();  // 100 MHz; when a path of this wave last ended
     for (uint32_t round = 0;; round++) {
         // Watchdog: a scheduling bug must end the launch, not hang the GPU.  It measures the time since a path
@@ -560,8 +672,38 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (slot == k && type != MAT_UNKNOWN) ? 1u : 0u;
             }
         }
+        // ---- restart, first half (exchange variant): close the paths that end here, then fill idle lanes from a
+        // pool that holds enough paths of one scatter class; the scatter steps below then run them
+        bool do_restart = false;
+        bool took[2] = {false, false};  // a batch came out of that class's pool this round: its scatter step runs now
+        if constexpr (XCHG) {
+            do_restart = wants(lane_wants_restart(w.cur), PH_IDLE);
+            const bool free_now = w.cur == LANE_IDLE || w.cur == LANE_EXIT;
+            if (do_restart || (exhausted && __ballot(free_now))) {
+                if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
+                if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
+                // the fuller pool first; a wave that has seen the queue empty takes whatever is left
+                const uint32_t first = pool_count(1) > pool_count(0) ? 1u : 0u;
+#pragma unroll
+                for (uint32_t pass = 0; pass < 2u; pass++) {
+                    const uint32_t cls = pass ? 1u - first : first;
+                    if (withdraw(cls, w.cur == LANE_IDLE || w.cur == LANE_EXIT, exhausted ? 1u : P.pool_min[cls])) ran = took[cls] = true;
+                }
+            }
+        }
         // ---- lambertian / metal
-        if (wants(w.cur == LANE_OPAQUE, PH_OPAQUE)) {
+        bool run_opaque = wants(w.cur == LANE_OPAQUE, PH_OPAQUE);
+        if constexpr (XCHG) {
+            if (took[0] && !run_opaque) {
+                run_opaque = true;
+                if (COUNT) ph_exec[PH_OPAQUE]++, ph_lanes[PH_OPAQUE] += (uint32_t)__popcll(__ballot(w.cur == LANE_OPAQUE));
+            }
+            if (!run_opaque && !force && !exhausted && (uint32_t)__popcll(__ballot(w.cur == LANE_OPAQUE)) >= P.pool_dep_min[0]) {
+                if (deposit(0u, w.cur == LANE_OPAQUE)) ran = true;
+                else run_opaque = true;  // the pool is full: the waves that empty it are behind
+            }
+        }
+        if (run_opaque) {
             ran = true;
             if (w.cur == LANE_OPAQUE) {
                 Hit hit;
@@ -576,7 +718,18 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             }
         }
         // ---- glass
-        if (wants(w.cur == LANE_GLASS, PH_GLASS)) {
+        bool run_glass = wants(w.cur == LANE_GLASS, PH_GLASS);
+        if constexpr (XCHG) {
+            if (took[1] && !run_glass) {
+                run_glass = true;
+                if (COUNT) ph_exec[PH_GLASS]++, ph_lanes[PH_GLASS] += (uint32_t)__popcll(__ballot(w.cur == LANE_GLASS));
+            }
+            if (!run_glass && !force && !exhausted && (uint32_t)__popcll(__ballot(w.cur == LANE_GLASS)) >= P.pool_dep_min[1]) {
+                if (deposit(1u, w.cur == LANE_GLASS)) ran = true;
+                else run_glass = true;
+            }
+        }
+        if (run_glass) {
             ran = true;
             if (w.cur == LANE_GLASS) {
                 Hit hit;
@@ -593,10 +746,13 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         // ---- restart: close the paths that end at this hit / miss, hand consecutive path ids from the
         // wave's chunk to lanes without a path, start the next sample.  One step on purpose: every
         // path needs both halves exactly once, and a separate state would only thin out the others.
-        if (wants(lane_wants_restart(w.cur), PH_IDLE)) {
+        if constexpr (!XCHG) do_restart = wants(lane_wants_restart(w.cur), PH_IDLE);
+        if (do_restart) {
             ran = true;
-            if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
-            if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
+            if constexpr (!XCHG) {
+                if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
+                if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
+            }
             unsigned long long m = __ballot(w.cur == LANE_IDLE);
             while (m) {
                 if (next == end) {
@@ -664,7 +820,15 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             }
         }
         if (!ran) {
-            if (__ballot(w.cur != LANE_EXIT) == 0ull) break;
+            if (__ballot(w.cur != LANE_EXIT) == 0ull) {
+                // Nothing left in this wave.  Parked paths are taken by waves that have seen the queue empty (this
+                // one has); a wave that parks one later has not, and will see it empty -- and take them -- itself.
+                if constexpr (XCHG) {
+                    if (pool_count(0) + pool_count(1) == 0u) break;
+                } else {
+                    break;
+                }
+            }
             force = true;
         } else {
             force = false;
@@ -685,6 +849,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             for (int k = 0; k < PH_COUNT; k++) {
                 atomicAdd(&P.counters[16 + 2 * k], (unsigned long long)ph_exec[k]);
                 atomicAdd(&P.counters[17 + 2 * k], (unsigned long long)ph_lanes[k]);
+            }
+            if constexpr (XCHG) {
+                atomicAdd(&P.counters[11], (unsigned long long)x_dep), atomicAdd(&P.counters[12], (unsigned long long)x_dep_lanes);
+                atomicAdd(&P.counters[13], (unsigned long long)x_wd), atomicAdd(&P.counters[14], (unsigned long long)x_wd_lanes);
             }
         }
     }
@@ -812,6 +980,20 @@ static void read_switches(Switches& s) {
     if (const char* e = getenv("MI355PT_CHUNK_RAYS")) s.chunk_rays = std::max(64.0f, (float)atof(e));
     if (const char* e = getenv("MI355PT_KERNEL")) s.lockstep = strcmp(e, "lockstep") == 0;
     s.watchdog_ms = (uint64_t)std::max(1l, env_long("MI355PT_WATCHDOG_MS", 20000));
+    s.exchange = env_long("MI355PT_XCHG", 0) != 0;
+    if (const char* e = getenv("MI355PT_XCHG_MIN")) {
+        unsigned a, b;
+        if (sscanf(e, "%u,%u", &a, &b) == 2) s.pool_min[0] = std::min(std::max(a, 1u), POOL_CAP), s.pool_min[1] = std::min(std::max(b, 1u), POOL_CAP);
+    }
+    if (const char* e = getenv("MI355PT_XCHG_DEP_MIN")) {
+        unsigned a, b;
+        if (sscanf(e, "%u,%u", &a, &b) == 2) s.pool_dep_min[0] = std::max(a, 1u), s.pool_dep_min[1] = std::max(b, 1u);
+    }
+    if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
+        unsigned t[6];
+        if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
+            for (int k = 0; k < 6; k++) s.xthr[k] = t[k] < 1 ? 1 : (t[k] > 65 ? 65 : t[k]);
+    }
     if (const char* senv = getenv("MI355PT_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -1048,6 +1230,9 @@ bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err
 template <int SCENE, bool COUNT, int BLK>
 static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, bool lockstep, std::string& err) {
     auto kern = lockstep ? pt_render_kernel<SCENE, COUNT, BLK> : pt_render_sched_kernel<SCENE, COUNT, BLK>;
+    if constexpr (SCENE == SCENE_LDS && BLK == 1024) {
+        if (P.pool_off && !lockstep) kern = pt_render_sched_kernel<SCENE, COUNT, BLK, true>;  // exchange variant
+    }
     if (lds_bytes > 48u * 1024u)
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    (int)lds_bytes));
@@ -1127,6 +1312,7 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     stats.tests = host_counters[1];
     stats.accepted = host_counters[2];
     for (int k = 0; k < 5; k++) stats.bounces[k] = host_counters[3 + k];
+    for (int k = 0; k < 4; k++) stats.exchange[k] = host_counters[11 + k];
     {
         unsigned long long slots[RAY_SLOTS * RAY_SLOT_STRIDE];
         PT_HIP(hipMemcpy(slots, d->ray_slots, sizeof slots, hipMemcpyDeviceToHost));
@@ -1266,6 +1452,16 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         if (!lockstep && long_launch && waves_per_cu(1024) > waves_per_cu(block)) block = 1024u;
         if (sw.block == 256 || sw.block == 512 || sw.block == 1024) block = sw.block;
         lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
+        // Exchange variant (paths waiting for a scatter step move between the waves of a workgroup through two
+        // pools in LDS): one sample per path, float nodes, 1024 lanes, and the pools must not cost a workgroup per CU.
+        if (sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 && !d->layout.node_half &&
+            lds_cu / (lds_bytes + POOL_BYTES) >= lds_cu / lds_bytes) {
+            P.pool_off = (lds_bytes + 15u) & ~15u;
+            lds_bytes = P.pool_off + POOL_BYTES;
+            P.pool_min[0] = sw.pool_min[0], P.pool_min[1] = sw.pool_min[1];
+            P.pool_dep_min[0] = sw.pool_dep_min[0], P.pool_dep_min[1] = sw.pool_dep_min[1];
+            for (int k = 0; k < 6; k++) P.thr[k] = sw.xthr[k];
+        }
     } else {
         // Scene in global memory.  LDS holds, per workgroup, the first stack entries of every lane and
         // as much of the top of the tree as still lets 24 waves stay resident on a CU.  Measured on
@@ -1412,6 +1608,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         } else {
             d->since_measure++;
         }
+        stats.exchange_on = P.pool_off != 0u;
         d->pending_launches++;
         d->pending_paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * nb;
     }

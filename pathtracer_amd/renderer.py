@@ -315,7 +315,8 @@ class Renderer:
     def stats(self):
         st = binding.Stats()
         self._check(lib().mi355pt_stats_get(self._ctx, C.byref(st)))
-        d = {name: getattr(st, name) for name, _ in binding.Stats._fields_ if name not in ("bounces", "phase")}
+        d = {name: getattr(st, name) for name, _ in binding.Stats._fields_ if name not in ("bounces", "phase", "exchange")}
+        d["exchange"] = dict(zip(["deposits", "lanes_deposited", "withdrawals", "lanes_withdrawn"], [int(x) for x in st.exchange]))
         d["bounces"] = dict(zip(["light", "lambertian", "metal", "glass", "sky"], [int(x) for x in st.bounces]))
         ph = [int(x) for x in st.phase]
         d["phases"] = {k: {"executions": ph[2 * i], "lanes": ph[2 * i + 1]}

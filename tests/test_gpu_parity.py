@@ -215,6 +215,31 @@ def test_frame_order_and_batching_do_not_change_bits(pa, monkeypatch):
     assert np.all(one[..., 3] == 1.0) and np.isfinite(one).all()
 
 
+def test_exchange_variant_is_bit_identical(pa, orc, monkeypatch):
+    # MI355PT_XCHG=1 runs the path kernel variant whose waves trade paths that wait for a scatter step through
+    # two pools in LDS (a measured experiment, off by default).  Which wave scatters a path must not change a bit.
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    W, H, seeds = 200, 112, [7, 8, 9, 10, 11]
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=8)
+    monkeypatch.setenv("MI355PT_XCHG", "1")
+    monkeypatch.setenv("MI355PT_BLOCK", "1024")
+    for mins, dep in (("48,32", "4,2"), ("2,2", "1,1"), ("64,64", "1,1")):   # defaults; constant traffic; full batches only
+        monkeypatch.setenv("MI355PT_XCHG_MIN", mins)
+        monkeypatch.setenv("MI355PT_XCHG_DEP_MIN", dep)
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=pa.FLAG_COUNT) as r:
+            r.render(seeds=seeds)
+            s = r.stats()
+            assert s["exchange_on"] == 1 and s["exchange"]["lanes_deposited"] == s["exchange"]["lanes_withdrawn"] > 0
+            assert bits_equal(ref, r.read_accum()) and s["rays"] == st["rays"]
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+            r.render(seeds=seeds)
+            assert bits_equal(ref, r.read_accum())
+    with pa.Renderer(sc, pa.Settings(3, 50), W, H) as r:     # several samples per path: the variant steps aside
+        r.render(seeds=seeds[:1])
+        assert r.stats()["exchange_on"] == 0
+
+
 def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
     # render_async queues launches without joining; frames must still be added in order, also when a
     # call is split into several launches (forced here: 64 frames per launch)
