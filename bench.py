@@ -62,6 +62,9 @@ def main():
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=256)
+    ap.add_argument("--total-frames", type=int, default=0,
+                    help="strong scaling: every step renders this many frames in total, split over the ranks "
+                         "(default 0: weak scaling, --frames-per-step frames per rank and step)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--scene", default=os.path.join(ROOT, "fixtures", "scene1.ron"))
@@ -107,10 +110,14 @@ def main():
     r = pa.Renderer(scene, settings, W, H, device=local_rank, base_seed=base_seed)
     acc_t = parallel.accum_tensor(r, local_rank) if use_dist else None
 
-    def step_seeds(step):
-        # global frame index: steps interleave ranks so every rank's frames are disjoint
-        first = (step * world + rank) * F
-        return parallel.seeds_for(base_seed, range(first, first + F), pa.frame_seed)
+    strong = args.total_frames > 0
+    step_frames = args.total_frames if strong else F * world   # frames all ranks render per step
+
+    def step_seeds(step, rank=rank, world=world):
+        # frames [step * step_frames, (step + 1) * step_frames) of one seed schedule, split over the ranks by
+        # mi355pt_partition_frames (contiguous blocks): weak scaling gives every rank F of them
+        return parallel.seeds_for(base_seed, parallel.rank_frames(step_frames, rank, world, first=step * step_frames),
+                                  pa.frame_seed)
 
     def sync():
         torch.cuda.synchronize()
@@ -149,11 +156,17 @@ def main():
             "metric": "Mrays/s", "value": rays_all / dt / 1e6, "unit": "Mrays/s",
             "mpaths_per_s": paths_all / dt / 1e6,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{os.path.basename(args.scene)} {W}x{H}, {F} frames/step x {args.steps} steps "
-                                   f"per GPU, 1 spp/frame, depth 50",
-                       "frames_per_gpu": F * args.steps, "paths_per_step_per_gpu": W * H * F,
+            "ms_per_step": dt * 1e3 / max(1, args.steps), "higher_is_better": True,
+            "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "f32",
+            "data": f"the reference's own scene file {os.path.basename(args.scene)}; frame seeds from a fixed schedule (base 0x00C0FFEE)",
+            "config": {"workload": (f"{os.path.basename(args.scene)} {W}x{H}, {step_frames} frames/step over all GPUs x "
+                                    f"{args.steps} steps, 1 spp/frame, depth 50" if strong else
+                                    f"{os.path.basename(args.scene)} {W}x{H}, {F} frames/step x {args.steps} steps "
+                                    f"per GPU, 1 spp/frame, depth 50"),
+                       "frames_per_step_all_gpus": step_frames,
+                       "frames_per_gpu": (step_frames * args.steps) // world if strong else F * args.steps,
+                       "paths_per_step_per_gpu": W * H * (step_frames // world),
                        "parallelism": f"frame-partitioned x{world}, one {'RCCL' if backend == 'nccl' else backend} sum-reduce"
                                       if world > 1 else "1 GPU",
                        "bvh": "binned SAH, 64-B two-child nodes", "scene_in_lds": bool(st["scene_in_lds"])},

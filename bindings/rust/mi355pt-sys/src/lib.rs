@@ -79,6 +79,9 @@ extern "C" {
     pub fn mi355pt_clear(ctx: *mut mi355pt_ctx) -> c_int;
     pub fn mi355pt_render(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
     pub fn mi355pt_render_async(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
+    pub fn mi355pt_partition_frames(total: u32, parts: u32, part: u32, first: *mut u32, count: *mut u32);
+    pub fn mi355pt_reduce(ctxs: *const *mut mi355pt_ctx, n: usize, root: usize) -> c_int;
+    pub fn mi355pt_reduce_comm(ctx: *mut mi355pt_ctx, nccl_comm: *mut c_void, root_rank: c_int, my_rank: c_int, total_frames: i32) -> c_int;
     pub fn mi355pt_render_static(ctx: *mut mi355pt_ctx, n_frames: u32, seeds: *const u32) -> c_int;
     pub fn mi355pt_wait(ctx: *mut mi355pt_ctx) -> c_int;
     pub fn mi355pt_frames(ctx: *const mi355pt_ctx) -> i32;

@@ -7,10 +7,11 @@ HIP device raises.
 from .binding import (BVH_LBVH, BVH_REFERENCE, BVH_SAH, FLAG_COUNT, FLAG_GLASS_SHORT_CIRCUIT, Mi355ptError, lib,
                       library_path)
 from .renderer import (CameraSettings, Renderer, SaveInfo, Scene, Settings, bvh_build_reference, camera_build,
-                       frame_seed, load_ron_scene, load_ron_settings, postprocess_rgb8, write_png_rgb8)
+                       frame_seed, load_ron_scene, load_ron_settings, partition_frames, postprocess_rgb8, reduce,
+                       write_png_rgb8)
 
 __all__ = [
     "BVH_LBVH", "BVH_REFERENCE", "BVH_SAH", "FLAG_COUNT", "FLAG_GLASS_SHORT_CIRCUIT", "Mi355ptError", "lib", "library_path",
     "CameraSettings", "Renderer", "SaveInfo", "Scene", "Settings", "bvh_build_reference", "camera_build",
-    "frame_seed", "load_ron_scene", "load_ron_settings", "postprocess_rgb8", "write_png_rgb8",
+    "frame_seed", "load_ron_scene", "load_ron_settings", "partition_frames", "postprocess_rgb8", "reduce", "write_png_rgb8",
 ]

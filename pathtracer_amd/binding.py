@@ -54,6 +54,9 @@ SIGNATURES = {
     "mi355pt_render_async": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mi355pt_render_static": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]),
     "mi355pt_wait": (C.c_int, [C.c_void_p]),
+    "mi355pt_partition_frames": (None, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "mi355pt_reduce": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t]),
+    "mi355pt_reduce_comm": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int32]),
     "mi355pt_frames": (C.c_int32, [C.c_void_p]),
     "mi355pt_read_accum": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t]),
     "mi355pt_write_accum": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, C.c_int32]),

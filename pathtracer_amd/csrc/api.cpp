@@ -49,7 +49,7 @@ struct mi355pt_ctx {
 
 namespace {
 
-std::string g_create_error;
+thread_local std::string g_create_error;  // failures without a context: per calling thread
 
 int fail(mi355pt_ctx* ctx, int code, const std::string& msg) {
     if (ctx) ctx->error = msg;
@@ -298,6 +298,58 @@ int mi355pt_render_static(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* see
     }
     c->frames += (int32_t)n_frames;
     c->seed_index += n_frames;
+    return MI355PT_OK;
+}
+
+void mi355pt_partition_frames(uint32_t total, uint32_t parts, uint32_t part, uint32_t* first, uint32_t* count) {
+    uint32_t f = 0, n = 0;
+    if (parts && part < parts) {  // contiguous blocks; the first total % parts blocks hold one frame more
+        const uint32_t q = total / parts, r = total % parts;
+        f = part * q + (part < r ? part : r);
+        n = q + (part < r ? 1u : 0u);
+    }
+    if (first) *first = f;
+    if (count) *count = n;
+}
+
+int mi355pt_reduce(mi355pt_ctx* const* ctxs, size_t n, size_t root) {
+    if (!ctxs || n == 0 || root >= n) return fail(nullptr, MI355PT_ERR_ARG, "reduce: bad arguments");
+    for (size_t i = 0; i < n; i++)
+        if (!ctxs[i]) return fail(nullptr, MI355PT_ERR_ARG, "reduce: null context");
+    mi355pt_ctx* r = ctxs[root];
+    std::vector<gpu::Device*> devs(n);
+    int64_t frames = 0;
+    for (size_t i = 0; i < n; i++) {
+        int rc = settle(ctxs[i]);
+        if (rc != MI355PT_OK) return i == root ? rc : fail(r, rc, "reduce: context " + std::to_string(i) + ": " + ctxs[i]->error);
+        if (ctxs[i]->dirty || ctxs[i]->frames < 0)
+            return fail(r, MI355PT_ERR_STATE, "reduce: context " + std::to_string(i) + " holds no rendered frames (its accumulator is due to be cleared)");
+        devs[i] = ctxs[i]->dev;
+        frames += ctxs[i]->frames;
+    }
+    std::string err;
+    if (!gpu::reduce_accum(devs.data(), n, root, err)) return fail(r, MI355PT_ERR_DEVICE, err);
+    for (size_t i = 0; i < n; i++) {
+        if (i == root) continue;
+        r->stats.paths += ctxs[i]->stats.paths, r->stats.rays += ctxs[i]->stats.rays;
+        ctxs[i]->dirty = true;  // its accumulator is spent: the next render starts a new accumulation
+    }
+    r->frames = (int32_t)frames;
+    return MI355PT_OK;
+}
+
+int mi355pt_reduce_comm(mi355pt_ctx* c, void* nccl_comm, int root_rank, int my_rank, int32_t total_frames) {
+    if (!c || !nccl_comm) return MI355PT_ERR_ARG;
+    SETTLE_OR_RETURN(c);
+    if (c->dirty || c->frames < 0) return fail(c, MI355PT_ERR_STATE, "reduce: no rendered frames (the accumulator is due to be cleared)");
+    std::string err;
+    if (!gpu::reduce_accum_comm(c->dev, nccl_comm, root_rank, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    if (my_rank == root_rank) {
+        if (!gpu::set_alpha(c->dev, 1.0f, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        c->frames = total_frames;
+    } else {
+        c->dirty = true;
+    }
     return MI355PT_OK;
 }
 

@@ -58,6 +58,16 @@ bool finish(Device* d, RenderStats& stats, std::string& err);
 constexpr uint32_t STATIC_MAX_FRAMES = 1024;
 bool render_static(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint32_t* seeds, uint32_t n_frames,
                    RenderStats& stats, std::string& err);
+// Sums the accumulators of n contexts (same image size, nothing in flight) into devs[root]'s: contexts that
+// share a device are added with a kernel, one accumulator per device is then summed by a single RCCL reduce
+// (one process, ncclCommInitAll over the devices involved; librccl.so is opened on first use).  The other
+// accumulators are left in an unspecified state.
+bool reduce_accum(Device* const* devs, size_t n, size_t root, std::string& err);
+// The same step for hosts that run one process per device and own the communicator: this context's part of an
+// ncclReduce(sum) to rank `root`, queued on its stream and waited for.  On ranks other than root the
+// accumulator is unchanged; on root the alpha channel holds the rank count afterwards (set_alpha puts 1 back).
+bool reduce_accum_comm(Device* d, void* nccl_comm, int root, std::string& err);
+bool set_alpha(Device* d, float alpha, std::string& err);
 bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
 void* accum_device_ptr(Device* d);

@@ -11,12 +11,15 @@
 //                           (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
 //   pt_tile_order_kernel    orders the 8x8 tiles by the rays they cost in the last launch
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types only: the library is opened at run time (see Rccl below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -235,9 +238,9 @@ __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0
 #pragma unroll
             for (uint32_t k = 0; k < 10; k++) *reinterpret_cast<PT_LDS(w2)*>(a + 8u * k) = w2{rec[2 * k], rec[2 * k + 1]};
         }
-        const uint32_t rest = (P.scene_lds_bytes - n * LDS_NODE_BYTES) / 16u;
+        const uint32_t rest = (P.scene_lds_bytes - lds_nodes_bytes(n)) / 16u;
         for (uint32_t i = threadIdx.x; i < rest; i += BLK)
-            *reinterpret_cast<PT_LDS(w4)*>(lds0 + n * LDS_NODE_BYTES + i * 16u) = src[n * 4u + i];
+            *reinterpret_cast<PT_LDS(w4)*>(lds0 + lds_nodes_bytes(n) + i * 16u) = src[n * 4u + i];
     } else {
         for (uint32_t i = threadIdx.x; i < P.scene_lds_bytes / 16u; i += BLK)
             *reinterpret_cast<PT_LDS(w4)*>(lds0 + i * 16u) = src[i];
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
     if constexpr (SCENE == SCENE_LDS) {
         mem.node_base = lds0;
-        mem.base = lds0 + P.L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+        mem.base = lds0 + lds_nodes_bytes(P.L.n_nodes) - P.L.n_nodes * (uint32_t)sizeof(Node64);
     } else if constexpr (LDS_SCENE) {
         mem.base = lds0;
     } else {
@@ -454,7 +457,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     stack.base = lds0 + P.scene_lds_bytes + threadIdx.x * 4u;
     if constexpr (SCENE == SCENE_LDS) {
         mem.node_base = lds0;
-        mem.base = lds0 + P.L.n_nodes * (LDS_NODE_BYTES - (uint32_t)sizeof(Node64));
+        mem.base = lds0 + lds_nodes_bytes(P.L.n_nodes) - P.L.n_nodes * (uint32_t)sizeof(Node64);
     } else if constexpr (LDS_SCENE) {
         mem.base = lds0;
     } else {
@@ -1643,6 +1646,173 @@ bool render_static(Device* d, const Camera64& cam, const RenderConfig& cfg, cons
     std::string err2;
     const bool done = finish(d, stats, queued ? err : err2);  // waits: the area and `seeds` are free again on return
     return queued && done;
+}
+
+// ------------------------------------------------------------------------------ accumulators of several devices
+__global__ void pt_add_rgb_kernel(f4* dst, const f4* src, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        f4 a = dst[i];
+        const f4 b = src[i];
+        a.x += b.x, a.y += b.y, a.z += b.z;
+        dst[i] = a;
+    }
+}
+__global__ void pt_set_alpha_kernel(f4* p, uint32_t n, float alpha) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i].w = alpha;
+}
+
+// RCCL, opened when first needed: the library works without it on one device.
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::map<std::vector<int>, std::vector<ncclComm_t>> comms;  // by device list; kept until the process ends
+};
+static std::mutex g_rccl_mutex;
+static Rccl g_rccl;
+static bool rccl_open(std::string& err) {
+    if (g_rccl.handle) return true;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+        err = std::string("reduce: cannot open librccl.so: ") + dlerror();
+        return false;
+    }
+    Rccl& r = g_rccl;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.Reduce = reinterpret_cast<decltype(r.Reduce)>(dlsym(h, "ncclReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.Reduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString) {
+        err = "reduce: librccl.so lacks an expected entry point";
+        dlclose(h);
+        return false;
+    }
+    r.handle = h;
+    return true;
+}
+#define PT_NCCL(call)                                                                   \
+    do {                                                                                \
+        ncclResult_t r_ = (call);                                                       \
+        if (r_ != ncclSuccess) {                                                        \
+            err = std::string(#call) + ": " + g_rccl.GetErrorString(r_);                \
+            return false;                                                               \
+        }                                                                               \
+    } while (0)
+
+static bool same_image(Device* const* devs, size_t n, std::string& err) {
+    for (size_t i = 0; i < n; i++) {
+        if (!devs[i] || !devs[i]->accum) {
+            err = "reduce: a context has no accumulator";
+            return false;
+        }
+        if (devs[i]->width != devs[0]->width || devs[i]->height != devs[0]->height) {
+            err = "reduce: the contexts differ in image size";
+            return false;
+        }
+    }
+    return true;
+}
+
+bool reduce_accum(Device* const* devs, size_t n, size_t root, std::string& err) {
+    if (n == 0 || root >= n) {
+        err = "reduce: root out of range";
+        return false;
+    }
+    if (!same_image(devs, n, err)) return false;
+    for (size_t i = 0; i < n; i++)
+        for (size_t j = 0; j < i; j++)
+            if (devs[i] == devs[j]) {
+                err = "reduce: a context is listed twice";
+                return false;
+            }
+    const uint32_t n_pix = devs[0]->n_pix;
+    const dim3 grid((n_pix + 255u) / 256u), block(256);
+    // Nothing is in flight on any of the contexts (the caller has joined them).  One context per device
+    // represents it -- the root on its device, the first listed elsewhere -- and first takes in the others that
+    // share its device with a plain kernel; RCCL then sums one accumulator per device into the root's.
+    std::map<int, Device*> rep;
+    rep[devs[root]->id] = devs[root];
+    for (size_t i = 0; i < n; i++) rep.emplace(devs[i]->id, devs[i]);
+    for (size_t i = 0; i < n; i++) {
+        Device* r = rep[devs[i]->id];
+        if (r == devs[i]) continue;
+        DeviceGuard guard(r->id);
+        hipLaunchKernelGGL(pt_add_rgb_kernel, grid, block, 0, r->stream, r->accum, devs[i]->accum, n_pix);
+        PT_HIP(hipGetLastError());
+    }
+    if (rep.size() > 1) {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!rccl_open(err)) return false;
+        std::vector<int> ids;
+        for (auto& kv : rep) ids.push_back(kv.first);  // ascending: the rank of a device is its place in this list
+        auto it = g_rccl.comms.find(ids);
+        if (it == g_rccl.comms.end()) {
+            std::vector<ncclComm_t> comms(ids.size());
+            PT_NCCL(g_rccl.CommInitAll(comms.data(), (int)ids.size(), ids.data()));
+            it = g_rccl.comms.emplace(ids, std::move(comms)).first;
+        }
+        int root_rank = 0;
+        for (size_t k = 0; k < ids.size(); k++)
+            if (ids[k] == devs[root]->id) root_rank = (int)k;
+        // one reduce of W*H*4 floats, every device's part queued on that device's render stream
+        PT_NCCL(g_rccl.GroupStart());
+        bool ok = true;
+        ncclResult_t bad = ncclSuccess;
+        for (size_t k = 0; k < ids.size() && ok; k++) {
+            Device* r = rep[ids[k]];
+            DeviceGuard guard(r->id);
+            bad = g_rccl.Reduce(r->accum, r->accum, (size_t)n_pix * 4u, ncclFloat, ncclSum, root_rank, it->second[k], r->stream);
+            ok = bad == ncclSuccess;
+        }
+        const ncclResult_t end = g_rccl.GroupEnd();
+        if (!ok || end != ncclSuccess) {
+            err = std::string("ncclReduce: ") + g_rccl.GetErrorString(ok ? end : bad);
+            return false;
+        }
+        // the alpha channel is the constant 1 of the clear colour in every accumulator, not a sum
+        DeviceGuard guard(devs[root]->id);
+        hipLaunchKernelGGL(pt_set_alpha_kernel, grid, block, 0, devs[root]->stream, devs[root]->accum, n_pix, 1.0f);
+        PT_HIP(hipGetLastError());
+    }
+    for (auto& kv : rep) {
+        DeviceGuard guard(kv.first);
+        PT_HIP(hipStreamSynchronize(kv.second->stream));
+    }
+    return true;
+}
+
+bool set_alpha(Device* d, float alpha, std::string& err) {
+    if (!d->accum) {
+        err = "no accumulator";
+        return false;
+    }
+    DeviceGuard guard(d->id);
+    hipLaunchKernelGGL(pt_set_alpha_kernel, dim3((d->n_pix + 255u) / 256u), dim3(256), 0, d->stream, d->accum, d->n_pix, alpha);
+    PT_HIP(hipGetLastError());
+    PT_HIP(hipStreamSynchronize(d->stream));
+    return true;
+}
+
+bool reduce_accum_comm(Device* d, void* comm, int root, std::string& err) {
+    if (!d->accum || !comm) {
+        err = "reduce: no accumulator or no communicator";
+        return false;
+    }
+    {
+        std::lock_guard<std::mutex> lock(g_rccl_mutex);
+        if (!rccl_open(err)) return false;
+    }
+    DeviceGuard guard(d->id);
+    PT_NCCL(g_rccl.Reduce(d->accum, d->accum, (size_t)d->n_pix * 4u, ncclFloat, ncclSum, root, static_cast<ncclComm_t>(comm), d->stream));
+    PT_HIP(hipStreamSynchronize(d->stream));
+    return true;
 }
 
 }  // namespace gpu

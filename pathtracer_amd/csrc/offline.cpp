@@ -6,20 +6,23 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "../../include/mi355pt.h"
 
 static void usage() {
     fprintf(stderr,
             "usage: mi355pt_offline [--scene scene1.ron] [--settings settings.ron] [--width 1280] [--height 720]\n"
-            "                       [--frames 1000] [--seed N] [--device 0] [--bvh sah|reference|lbvh] [--out img.png]\n"
-            "                       [--chunk 50]\n");
+            "                       [--frames 1000] [--seed N] [--device 0 | --devices 0,1,...] [--bvh sah|reference|lbvh]\n"
+            "                       [--out img.png] [--chunk 50]\n"
+            "  --devices: the frames are split over one context per listed device (a device may be listed more than\n"
+            "             once) and the accumulators are summed into the first one's before the image is written\n");
 }
 
 int main(int argc, char** argv) {
     std::string scene_path = "scene1.ron", settings_path = "settings.ron", out = "img.png", bvh = "sah";
     uint32_t width = 1280, height = 720, frames = 1000, seed = 0x00C0FFEEu, chunk = 50;
-    int device = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto next = [&](const char* name) -> const char* {
@@ -35,7 +38,19 @@ int main(int argc, char** argv) {
         else if (a == "--height") height = (uint32_t)strtoul(next("--height"), nullptr, 0);
         else if (a == "--frames") frames = (uint32_t)strtoul(next("--frames"), nullptr, 0);
         else if (a == "--seed") seed = (uint32_t)strtoul(next("--seed"), nullptr, 0);
-        else if (a == "--device") device = atoi(next("--device"));
+        else if (a == "--device") devices.assign(1, atoi(next("--device")));
+        else if (a == "--devices") {
+            devices.clear();
+            for (const char* p = next("--devices"); *p;) {
+                char* end = nullptr;
+                devices.push_back((int)strtol(p, &end, 10));
+                if (end == p) {
+                    fprintf(stderr, "--devices wants a comma-separated list of device ordinals\n");
+                    return 2;
+                }
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--bvh") bvh = next("--bvh");
         else if (a == "--out") out = next("--out");
         else if (a == "--chunk") chunk = (uint32_t)strtoul(next("--chunk"), nullptr, 0);
@@ -61,33 +76,62 @@ int main(int argc, char** argv) {
         return 1;
     }
 
-    mi355pt_desc desc;
-    memset(&desc, 0, sizeof desc);
-    desc.width = width, desc.height = height, desc.device = device, desc.base_seed = seed;
-    desc.bvh_mode = bvh == "reference" ? MI355PT_BVH_REFERENCE : (bvh == "lbvh" ? MI355PT_BVH_LBVH : MI355PT_BVH_SAH);
-    mi355pt_ctx* ctx = nullptr;
-    if (mi355pt_create(&desc, &ctx) != MI355PT_OK) {
-        fprintf(stderr, "error: %s\n", mi355pt_last_error(nullptr));
-        return 1;
-    }
-    if (mi355pt_set_settings(ctx, samples, depth) != MI355PT_OK || mi355pt_set_scene_handle(ctx, scene) != MI355PT_OK) {
-        fprintf(stderr, "error: %s\n", mi355pt_last_error(ctx));
-        return 1;
-    }
-    mi355pt_scene_free(scene);
-
-    // offline.rs:44-63: one frame per iteration there; a chunk of frames per call here
-    for (uint32_t done = 0; done < frames;) {
-        uint32_t n = frames - done < chunk ? frames - done : chunk;
-        if (mi355pt_render(ctx, n, nullptr) != MI355PT_OK) {
-            fprintf(stderr, "\nerror: %s\n", mi355pt_last_error(ctx));
+    if (devices.empty()) devices.push_back(0);
+    const uint32_t n_ctx = (uint32_t)devices.size();
+    std::vector<mi355pt_ctx*> ctxs(n_ctx, nullptr);
+    for (uint32_t k = 0; k < n_ctx; k++) {
+        mi355pt_desc desc;
+        memset(&desc, 0, sizeof desc);
+        desc.width = width, desc.height = height, desc.device = devices[k], desc.base_seed = seed;
+        desc.bvh_mode = bvh == "reference" ? MI355PT_BVH_REFERENCE : (bvh == "lbvh" ? MI355PT_BVH_LBVH : MI355PT_BVH_SAH);
+        if (mi355pt_create(&desc, &ctxs[k]) != MI355PT_OK) {
+            fprintf(stderr, "error: %s\n", mi355pt_last_error(nullptr));
             return 1;
         }
-        done += n;
+        if (mi355pt_set_settings(ctxs[k], samples, depth) != MI355PT_OK || mi355pt_set_scene_handle(ctxs[k], scene) != MI355PT_OK) {
+            fprintf(stderr, "error: %s\n", mi355pt_last_error(ctxs[k]));
+            return 1;
+        }
+    }
+    mi355pt_scene_free(scene);
+    mi355pt_ctx* ctx = ctxs[0];
+
+    // offline.rs:44-63: one frame per iteration there; here every context renders its block of the frame
+    // range (mi355pt_partition_frames) a chunk at a time, all devices working on their chunks at once
+    std::vector<uint32_t> first(n_ctx), count(n_ctx), done_k(n_ctx, 0);
+    for (uint32_t k = 0; k < n_ctx; k++) mi355pt_partition_frames(frames, n_ctx, k, &first[k], &count[k]);
+    std::vector<uint32_t> seeds;
+    for (uint32_t done = 0; done < frames;) {
+        for (uint32_t k = 0; k < n_ctx; k++) {
+            const uint32_t n = count[k] - done_k[k] < chunk ? count[k] - done_k[k] : chunk;
+            if (n == 0) continue;
+            seeds.resize(n);  // frame f of the whole render has the seed a one-device render gives it
+            for (uint32_t j = 0; j < n; j++) seeds[j] = mi355pt_frame_seed(seed, first[k] + done_k[k] + j);
+            if (mi355pt_render_async(ctxs[k], n, seeds.data()) != MI355PT_OK) {
+                fprintf(stderr, "\nerror: %s\n", mi355pt_last_error(ctxs[k]));
+                return 1;
+            }
+            done_k[k] += n, done += n;
+        }
+        for (uint32_t k = 0; k < n_ctx; k++)
+            if (mi355pt_wait(ctxs[k]) != MI355PT_OK) {
+                fprintf(stderr, "\nerror: %s\n", mi355pt_last_error(ctxs[k]));
+                return 1;
+            }
         fprintf(stderr, "\r%u/%u | %.1f%% ", done, frames, (float)done / (float)frames * 100.0f);
         fflush(stderr);
     }
     fprintf(stderr, "\n");
+    if (n_ctx > 1 && frames > 0) {
+        // contexts that got no frame (more devices than frames) stay out of the sum
+        std::vector<mi355pt_ctx*> used;
+        for (uint32_t k = 0; k < n_ctx; k++)
+            if (count[k]) used.push_back(ctxs[k]);
+        if (mi355pt_reduce(used.data(), used.size(), 0) != MI355PT_OK) {
+            fprintf(stderr, "error: %s\n", mi355pt_last_error(ctx));
+            return 1;
+        }
+    }
 
     printf("Img size: %u, %u\n", width, height);
     printf("Samples: %lld\n", (long long)frames * samples);
@@ -97,9 +141,9 @@ int main(int argc, char** argv) {
     }
     mi355pt_stats st;
     if (mi355pt_stats_get(ctx, &st) == MI355PT_OK && st.render_ms > 0.0)
-        fprintf(stderr, "device: %.1f ms in path kernels, %.1f Mpaths/s, %.1f Mrays/s\n", st.render_ms,
-                (double)st.paths / st.render_ms / 1e3, (double)st.rays / st.render_ms / 1e3);
-    mi355pt_destroy(ctx);
+        fprintf(stderr, "device %d: %.1f ms in path kernels; %llu paths, %llu rays on %u context(s)\n", devices[0], st.render_ms,
+                (unsigned long long)st.paths, (unsigned long long)st.rays, n_ctx);
+    for (mi355pt_ctx* c : ctxs) mi355pt_destroy(c);
     auto secs = std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - t0).count();
     printf("Time took: %llds\n", (long long)secs);
     return 0;

@@ -178,7 +178,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     L = SceneLayout{};
     const char* nenv = getenv("MI355PT_NODES");
     const bool force_half = nenv && strcmp(nenv, "half") == 0, force_float = nenv && strcmp(nenv, "float") == 0;
-    const bool lds_with_float = bvh.nodes.size() * LDS_NODE_BYTES + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
+    const bool lds_with_float = lds_nodes_bytes((uint32_t)bvh.nodes.size()) + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
     const bool lds_with_half = bvh.nodes.size() * sizeof(Node32) + rest_bytes + stack256 <= LDS_SCENE_LIMIT;
     const bool reference_walk = caller_tree || reference_topology;
     if (!reference_walk && lds_with_half && !force_float && (!lds_with_float || force_half)) {

@@ -9,11 +9,13 @@ float additions across ranks differs.
 import numpy as np
 
 
-def rank_frames(n_frames, rank, world):
-    """Global frame indices rendered by `rank`: contiguous blocks, sizes differ by at most one."""
-    base, extra = divmod(int(n_frames), int(world))
-    start = rank * base + min(rank, extra)
-    return range(start, start + base + (1 if rank < extra else 0))
+def rank_frames(n_frames, rank, world, first=0):
+    """Global frame indices rendered by `rank` out of frames [first, first + n_frames): contiguous blocks,
+    sizes differ by at most one -- the library's own split (mi355pt_partition_frames), which the offline
+    CLI, bench.py and the tests all use."""
+    from .renderer import partition_frames
+    start, count = partition_frames(n_frames, world, rank)
+    return range(first + start, first + start + count)
 
 
 class _DevicePtr:

@@ -139,6 +139,21 @@ def bvh_build_reference(spheres, swap_mode=0, swap_seed=1):
     return nodes[:r]
 
 
+def partition_frames(total, parts, part):
+    """(first, count) of the frames part `part` of `parts` renders: mi355pt_partition_frames."""
+    first, count = C.c_uint32(0), C.c_uint32(0)
+    lib().mi355pt_partition_frames(int(total), int(parts), int(part), C.byref(first), C.byref(count))
+    return first.value, count.value
+
+
+def reduce(renderers, root=0):
+    """mi355pt_reduce: sums the accumulators of several Renderers (one process, any devices) into renderers[root]."""
+    arr = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
+    rc = lib().mi355pt_reduce(arr, len(renderers), int(root))
+    if rc != 0:
+        raise Mi355ptError(rc, lib().mi355pt_last_error(renderers[root]._ctx).decode(errors="replace"))
+
+
 def frame_seed(base_seed, frame):
     return int(lib().mi355pt_frame_seed(base_seed & 0xFFFFFFFF, frame & 0xFFFFFFFF))
 

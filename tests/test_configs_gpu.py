@@ -1,0 +1,146 @@
+"""The stated configurations at their stated sizes (C1-C4), the offline CLI and the several-device verbs, on the GPU
+through the C ABI.  Where the oracle covers the whole input the accumulator bits must be equal; at full sizes the
+checks are properties that do not depend on it (split-invariance, counts, alpha, finiteness) plus an oracle crop."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import FIXTURES, ROOT, bits_equal, oracle_scene
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "pathtracer_amd", "mi355pt_offline")
+
+
+def seeds_of(pa, n, first=0, base=0x00C0FFEE):
+    return np.array([pa.frame_seed(base, first + k) for k in range(n)], np.uint32)
+
+
+def test_c1_scene1_400x225x16_whole_image(pa, orc):
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    W, H, seeds = 400, 225, seeds_of(pa, 16)
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
+    for mode in (pa.BVH_SAH, pa.BVH_REFERENCE, pa.BVH_LBVH):
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=mode) as r:
+            r.render(16)                                    # the library's own seed schedule
+            assert bits_equal(ref, r.read_accum()) and r.stats()["rays"] == st["rays"] and r.samples() == 16
+
+
+def full_size_properties(pa, orc, sc, W, H, frames, crop, exact=True):
+    seeds = seeds_of(pa, frames)
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        r.render(seeds=seeds)
+        a, s = r.read_accum(), r.stats()
+        r.clear()
+        cut = frames // 3
+        r.render(seeds=seeds[:cut])
+        r.render(seeds=seeds[cut:], wait=False)
+        b = r.read_accum()
+    assert bits_equal(a, b)                                   # split- and queue-invariant
+    assert np.all(a[..., 3] == 1.0) and np.isfinite(a).all() and a[..., :3].min() >= 0.0
+    assert s["paths"] == W * H * frames and s["paths"] <= s["rays"] <= 51 * s["paths"]
+    osc = oracle_scene(orc, sc)
+    x0, x1, y0, y1 = crop
+    ref, _ = orc.render(osc, osc.camera(W, H), W, H, seeds, crop=crop, threads=16)
+    if exact:
+        assert bits_equal(ref[y0:y1, x0:x1], a[y0:y1, x0:x1])
+    else:
+        differ = (ref[y0:y1, x0:x1].view(np.uint32) != a[y0:y1, x0:x1].view(np.uint32)).any(axis=2)
+        assert differ.sum() * 1000 <= differ.size
+    return s
+
+
+@pytest.mark.parametrize("name", ["scene2.ron", "scene3.ron"])
+def test_c3_small_scenes_1080p_256_frames(pa, orc, name):
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, name))
+    s = full_size_properties(pa, orc, sc, 1920, 1080, 256, (928, 992, 520, 552))
+    assert s["scene_in_lds"] == 1
+
+
+def test_c4_million_spheres_4k(pa, orc):
+    # 3840x2160, 64 frames of the 256 (the oracle's crop sets the time); the crop lies below the horizon rows,
+    # where the default tree and the reference's agree bit for bit (see test_million_spheres_within_the_stated_bound)
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(1_000_000)
+    s = full_size_properties(pa, orc, sc, 3840, 2160, 64, (1900, 1932, 1500, 1516), exact=False)
+    assert s["scene_in_lds"] == 0
+
+
+def run_cli(*args, cwd):
+    return subprocess.run([CLI, *args], cwd=cwd, capture_output=True, text=True, timeout=300)
+
+
+def test_offline_cli(pa, tmp_path):
+    from PIL import Image
+    scene, settings = os.path.join(FIXTURES, "scene1.ron"), os.path.join(FIXTURES, "settings.ron")
+    W, H, F = 320, 180, 24
+    p = run_cli("--scene", scene, "--settings", settings, "--width", str(W), "--height", str(H), "--frames", str(F),
+                "--out", "a.png", "--chunk", "7", cwd=tmp_path)
+    assert p.returncode == 0, p.stderr
+    lines = p.stdout.strip().splitlines()                     # offline.rs:75-83
+    assert lines[0] == f"Img size: {W}, {H}" and lines[1] == f"Samples: {F}" and lines[2].startswith("Time took: ")
+    assert lines[2].endswith("s") and f"{F}/{F} | 100.0% " in p.stderr      # offline.rs:54-60
+    sc = pa.load_ron_scene(scene)
+    with pa.Renderer(sc, pa.load_ron_settings(settings), W, H) as r:
+        r.render(F)
+        want = r.to_rgb8()
+    got = np.asarray(Image.open(tmp_path / "a.png").convert("RGB"))
+    assert np.array_equal(got, want)                          # SaveInfo::finish's bytes
+    # the frames split over three contexts (here on one device): the same image up to the order of the additions
+    p = run_cli("--scene", scene, "--settings", settings, "--width", str(W), "--height", str(H), "--frames", str(F),
+                "--out", "b.png", "--devices", "0,0,0", cwd=tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert p.stdout.splitlines()[1] == f"Samples: {F}"
+    split = np.asarray(Image.open(tmp_path / "b.png").convert("RGB")).astype(int)
+    assert np.abs(split - want.astype(int)).max() <= 1 and np.count_nonzero(split != want) <= split.size // 1000
+    # offline.rs:37: a scene that cannot be loaded falls back to Scene::default() (scene.rs:15-31)
+    p = run_cli("--scene", "no_such_scene.ron", "--settings", settings, "--width", "64", "--height", "36", "--frames", "2",
+                "--out", "d.png", cwd=tmp_path)
+    assert p.returncode == 0 and "default scene" in p.stderr
+    from pathtracer_amd.renderer import Scene
+    with pa.Renderer(Scene.default(), pa.load_ron_settings(settings), 64, 36) as r:
+        r.render(2)
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "d.png").convert("RGB")), r.to_rgb8())
+    # offline.rs:39: missing settings end the run (unwrap() there, exit status 1 here), nothing is written
+    p = run_cli("--scene", scene, "--settings", "no_such_settings.ron", "--out", "e.png", cwd=tmp_path)
+    assert p.returncode == 1 and "error" in p.stderr and not (tmp_path / "e.png").exists()
+    # with no flags the reference's file names are looked up in the working directory
+    p = run_cli("--frames", "1", "--width", "32", "--height", "18", cwd=FIXTURES)
+    assert p.returncode == 0 and os.path.exists(os.path.join(FIXTURES, "img.png"))
+    os.remove(os.path.join(FIXTURES, "img.png"))
+
+
+def test_reduce_over_contexts(pa):
+    # mi355pt_reduce with every context on this box's one device: the same-device path of the verb; the frame
+    # split is mi355pt_partition_frames.  Against one context rendering all frames only the order of the float
+    # additions differs (bound: 1e-6 relative).
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    W, H, F, N = 256, 144, 50, 3
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        r.render(F)
+        one, st_one = r.read_accum(), r.stats()
+    rs = [pa.Renderer(sc, pa.Settings(1, 50), W, H) for _ in range(N)]
+    try:
+        for k, r in enumerate(rs):
+            first, count = pa.partition_frames(F, N, k)
+            r.render(seeds=seeds_of(pa, count, first), wait=False)
+        pa.reduce(rs, root=1)
+        acc, st = rs[1].read_accum(), rs[1].stats()
+        assert rs[1].samples() == F and st["paths"] == st_one["paths"] and st["rays"] == st_one["rays"]
+        assert np.all(acc[..., 3] == 1.0)
+        rel = np.abs(acc[..., :3] - one[..., :3]) / np.maximum(1.0, np.abs(one[..., :3]))
+        assert rel.max() <= 2e-6 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 1e-6
+        assert np.array_equal(rs[1].to_rgb8(), pa.postprocess_rgb8(acc, F))
+        rs[0].render(seeds=[1])                               # a spent context starts over
+        assert rs[0].samples() == 1
+        with pytest.raises(pa.Mi355ptError):
+            pa.reduce([rs[1], rs[1]], root=0)
+        # a group of one is the identity
+        before = rs[1].read_accum()
+        pa.reduce([rs[1]], root=0)
+        assert bits_equal(before, rs[1].read_accum()) and rs[1].samples() == F
+    finally:
+        for r in rs:
+            r.close()

@@ -404,7 +404,7 @@ def test_ten_million_spheres_reference_walk(pa, orc):
     ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
     acc, gs = gpu_render(pa, sc, W, H, seeds)
     differ = (acc.view(np.uint32) != ref.view(np.uint32)).any(axis=2)
-    assert differ.sum() * 100 < W * H              # under 1 % with the default tree
+    assert differ.sum() * 1000 <= 3 * W * H        # measured: 33 of 14 400 at 160x90 (0.23 %); bound 0.3 %
     acc_r, gs_r = gpu_render(pa, sc, W, H, seeds, bvh_mode=pa.BVH_REFERENCE)
     assert bits_equal(ref, acc_r) and gs_r["rays"] == st["rays"]
 

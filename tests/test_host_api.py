@@ -212,3 +212,20 @@ def test_synthetic_plane_scene_is_deterministic_and_valid(pa):
     assert np.all(a.glass >= 1.0) and np.all(a.glass < 4.0)
     assert np.all(a.metals["w"] <= 0.5)
     assert abs(float(a.camera.yaw) - (-102.99461)) < 1e-3 and abs(float(a.camera.pitch) - (-8.525517)) < 1e-3
+
+
+def test_frame_partition_is_exact(pa):
+    # mi355pt_partition_frames: contiguous blocks that tile [0, total), sizes differ by at most one; the Python
+    # helper the multi-process path uses is the same function
+    from pathtracer_amd import parallel
+    for total in (0, 1, 7, 256, 1000, 16384):
+        for parts in (1, 2, 3, 8, 13):
+            at, sizes = 0, []
+            for k in range(parts):
+                first, count = pa.partition_frames(total, parts, k)
+                assert first == at
+                assert list(parallel.rank_frames(total, k, parts, first=100)) == list(range(100 + first, 100 + first + count))
+                at += count
+                sizes.append(count)
+            assert at == total and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert pa.partition_frames(10, 0, 0) == (0, 0) and pa.partition_frames(10, 2, 2) == (0, 0)
