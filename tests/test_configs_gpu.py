@@ -144,3 +144,31 @@ def test_reduce_over_contexts(pa):
     finally:
         for r in rs:
             r.close()
+
+
+def test_reduce_comm_with_a_one_rank_rccl_communicator(pa):
+    # mi355pt_reduce_comm with a communicator the caller made (here: RCCL's ncclCommInitAll over this box's one
+    # device, through ctypes): the ncclReduce the library issues on the context's stream, on a group of one, must
+    # leave the sums as they are, put alpha back to 1 and record the frame total.  What a box with one GPU can
+    # exercise of the RCCL path; a reduce between two physical GPUs needs a larger machine.
+    import ctypes as C
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+    comm = C.c_void_p()
+    devs = (C.c_int * 1)(0)
+    assert rccl.ncclCommInitAll(C.byref(comm), 1, devs) == 0
+    try:
+        sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene3.ron"))
+        with pa.Renderer(sc, pa.Settings(1, 50), 128, 72) as r:
+            r.render(5)
+            before = r.read_accum()
+            rc = pa.lib().mi355pt_reduce_comm(r._ctx, comm, 0, 0, 5)
+            assert rc == 0, pa.lib().mi355pt_last_error(r._ctx)
+            assert bits_equal(before, r.read_accum()) and r.samples() == 5
+            r.render(2)                                        # the root keeps accumulating
+            assert r.samples() == 7
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
