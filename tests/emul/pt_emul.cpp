@@ -61,7 +61,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     if (ordered) {
         ordered_nodes.resize((size_t)L.n_nodes * LDS_NODE_BYTES);
         for (uint32_t i = 0; i < L.n_nodes; i++) {
-            uint32_t q[16], rec[20];
+            uint32_t q[16], rec[LDS_NODE_BYTES / 4u] = {0};
             memcpy(q, blob.data() + L.off_nodes + (size_t)i * 64u, 64);
             const uint32_t l0 = (int32_t)q[12] >= 0 ? q[12] * LDS_NODE_BYTES : q[12];
             const uint32_t l1 = (int32_t)q[13] >= 0 ? q[13] * LDS_NODE_BYTES : q[13];
