@@ -104,6 +104,21 @@ void rebuild_camera(mi355pt_ctx* c) {
     }
 }
 
+// Nothing may unwind through the C ABI: allocation failures of the host-side copies and builders (million-sphere
+// scenes) and anything unexpected become error codes.
+template <class F>
+int guarded(mi355pt_ctx* ctx, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(ctx, MI355PT_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(ctx, MI355PT_ERR_DEVICE, std::string("unexpected failure: ") + e.what());
+    } catch (...) {
+        return fail(ctx, MI355PT_ERR_DEVICE, "unexpected failure");
+    }
+}
+
 void copy_err(const std::string& e, char* buf, size_t len) {
     if (!buf || !len) return;
     size_t n = e.size() < len - 1 ? e.size() : len - 1;
@@ -116,26 +131,28 @@ void copy_err(const std::string& e, char* buf, size_t len) {
 extern "C" {
 
 int mi355pt_create(const mi355pt_desc* desc, mi355pt_ctx** out) {
-    if (!desc || !out) return fail(nullptr, MI355PT_ERR_ARG, "create: null argument");
-    *out = nullptr;
-    if (desc->width == 0 || desc->height == 0) return fail(nullptr, MI355PT_ERR_ARG, "create: zero image size");
-    if (desc->bvh_mode > MI355PT_BVH_LBVH) return fail(nullptr, MI355PT_ERR_ARG, "create: unknown bvh_mode");
-    mi355pt_ctx* c = new (std::nothrow) mi355pt_ctx();
-    if (!c) return fail(nullptr, MI355PT_ERR_NOMEM, "create: out of memory");
-    c->desc = *desc;
-    std::string err;
-    if (!gpu::create(desc->device, desc->stream, &c->dev, err)) {
-        delete c;
-        return fail(nullptr, MI355PT_ERR_DEVICE, err);
-    }
-    c->width = desc->width, c->height = desc->height;
-    if (!gpu::resize(c->dev, c->width, c->height, err)) {
-        gpu::destroy(c->dev);
-        delete c;
-        return fail(nullptr, MI355PT_ERR_DEVICE, err);
-    }
-    *out = c;
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!desc || !out) return fail(nullptr, MI355PT_ERR_ARG, "create: null argument");
+        *out = nullptr;
+        if (desc->width == 0 || desc->height == 0) return fail(nullptr, MI355PT_ERR_ARG, "create: zero image size");
+        if (desc->bvh_mode > MI355PT_BVH_LBVH) return fail(nullptr, MI355PT_ERR_ARG, "create: unknown bvh_mode");
+        mi355pt_ctx* c = new (std::nothrow) mi355pt_ctx();
+        if (!c) return fail(nullptr, MI355PT_ERR_NOMEM, "create: out of memory");
+        c->desc = *desc;
+        std::string err;
+        if (!gpu::create(desc->device, desc->stream, &c->dev, err)) {
+            delete c;
+            return fail(nullptr, MI355PT_ERR_DEVICE, err);
+        }
+        c->width = desc->width, c->height = desc->height;
+        if (!gpu::resize(c->dev, c->width, c->height, err)) {
+            gpu::destroy(c->dev);
+            delete c;
+            return fail(nullptr, MI355PT_ERR_DEVICE, err);
+        }
+        *out = c;
+        return MI355PT_OK;
+    });
 }
 
 void mi355pt_destroy(mi355pt_ctx* ctx) {
@@ -150,39 +167,43 @@ const char* mi355pt_last_error(const mi355pt_ctx* ctx) { return ctx ? ctx->error
 int mi355pt_set_scene(mi355pt_ctx* c, const void* spheres32, size_t n_spheres, const void* lights16, size_t n_lights,
                       const void* lambertians16, size_t n_lambertians, const void* metals16, size_t n_metals,
                       const void* glass4, size_t n_glass) {
-    if (!c) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    {
-        SceneArrays a;
-        a.spheres = static_cast<const Sphere32*>(spheres32), a.n_spheres = n_spheres;
-        a.lights = static_cast<const Vec16*>(lights16), a.n_lights = n_lights;
-        a.lambertians = static_cast<const Vec16*>(lambertians16), a.n_lambertians = n_lambertians;
-        a.metals = static_cast<const Vec16*>(metals16), a.n_metals = n_metals;
-        a.glass = static_cast<const float*>(glass4), a.n_glass = n_glass;
-        std::string err;
-        if (!validate_scene(a, err)) return fail(c, MI355PT_ERR_ARG, err);
-    }
-    const Sphere32* sp = static_cast<const Sphere32*>(spheres32);
-    c->have_scene = false;
-    c->spheres.assign(sp, sp + n_spheres);
-    auto vec16 = [](const void* p, size_t n) {
-        const Vec16* v = static_cast<const Vec16*>(p);
-        return n ? std::vector<Vec16>(v, v + n) : std::vector<Vec16>();
-    };
-    c->lights = vec16(lights16, n_lights);
-    c->lambertians = vec16(lambertians16, n_lambertians);
-    c->metals = vec16(metals16, n_metals);
-    const float* g = static_cast<const float*>(glass4);
-    c->glass = n_glass ? std::vector<float>(g, g + n_glass) : std::vector<float>();
-    return install_tree(c, nullptr, 0);
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        {
+            SceneArrays a;
+            a.spheres = static_cast<const Sphere32*>(spheres32), a.n_spheres = n_spheres;
+            a.lights = static_cast<const Vec16*>(lights16), a.n_lights = n_lights;
+            a.lambertians = static_cast<const Vec16*>(lambertians16), a.n_lambertians = n_lambertians;
+            a.metals = static_cast<const Vec16*>(metals16), a.n_metals = n_metals;
+            a.glass = static_cast<const float*>(glass4), a.n_glass = n_glass;
+            std::string err;
+            if (!validate_scene(a, err)) return fail(c, MI355PT_ERR_ARG, err);
+        }
+        const Sphere32* sp = static_cast<const Sphere32*>(spheres32);
+        c->have_scene = false;
+        c->spheres.assign(sp, sp + n_spheres);
+        auto vec16 = [](const void* p, size_t n) {
+            const Vec16* v = static_cast<const Vec16*>(p);
+            return n ? std::vector<Vec16>(v, v + n) : std::vector<Vec16>();
+        };
+        c->lights = vec16(lights16, n_lights);
+        c->lambertians = vec16(lambertians16, n_lambertians);
+        c->metals = vec16(metals16, n_metals);
+        const float* g = static_cast<const float*>(glass4);
+        c->glass = n_glass ? std::vector<float>(g, g + n_glass) : std::vector<float>();
+        return install_tree(c, nullptr, 0);
+    });
 }
 
 int mi355pt_set_bvh(mi355pt_ctx* c, const void* nodes48, size_t n_nodes) {
-    if (!c) return MI355PT_ERR_ARG;
-    if (c->spheres.empty()) return fail(c, MI355PT_ERR_STATE, "set_bvh: call set_scene first");
-    if (!nodes48) return fail(c, MI355PT_ERR_ARG, "set_bvh: null nodes");
-    SETTLE_OR_RETURN(c);
-    return install_tree(c, static_cast<const Node48*>(nodes48), n_nodes);
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        if (c->spheres.empty()) return fail(c, MI355PT_ERR_STATE, "set_bvh: call set_scene first");
+        if (!nodes48) return fail(c, MI355PT_ERR_ARG, "set_bvh: null nodes");
+        SETTLE_OR_RETURN(c);
+        return install_tree(c, static_cast<const Node48*>(nodes48), n_nodes);
+    });
 }
 
 int mi355pt_set_camera(mi355pt_ctx* c, const void* camera64) {
@@ -220,85 +241,93 @@ int mi355pt_set_settings(mi355pt_ctx* c, int32_t samples, int32_t depth) {
 }
 
 int mi355pt_resize(mi355pt_ctx* c, uint32_t width, uint32_t height) {
-    if (!c) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    std::string err;
-    if (!gpu::resize(c->dev, width, height, err)) return fail(c, MI355PT_ERR_DEVICE, err);
-    c->width = width, c->height = height;
-    c->dirty = true;
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        std::string err;
+        if (!gpu::resize(c->dev, width, height, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        c->width = width, c->height = height;
+        c->dirty = true;
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_clear(mi355pt_ctx* c) {
-    if (!c) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    std::string err;
-    rebuild_camera(c);
-    if (!gpu::clear(c->dev, err)) return fail(c, MI355PT_ERR_DEVICE, err);
-    c->dirty = false;
-    c->frames = 0;
-    c->seed_index = 0;
-    c->stats = gpu::RenderStats{};
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        std::string err;
+        rebuild_camera(c);
+        if (!gpu::clear(c->dev, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        c->dirty = false;
+        c->frames = 0;
+        c->seed_index = 0;
+        c->stats = gpu::RenderStats{};
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
-    if (!c) return MI355PT_ERR_ARG;
-    if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
-    if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
-    if (c->dirty) {  // mod.rs:169-195
-        int r = mi355pt_clear(c);
-        if (r != MI355PT_OK) return r;
-    }
-    if (n_frames == 0) return MI355PT_OK;
-    std::vector<uint32_t> own;
-    if (!seeds) {
-        own.resize(n_frames);
-        for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
-        seeds = own.data();
-    }
-    gpu::RenderConfig cfg;
-    cfg.samples = c->settings.samples;
-    cfg.depth = c->settings.depth;
-    cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
-    cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
-    std::string err;
-    if (!gpu::enqueue(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
-    c->frames += (int32_t)n_frames;
-    c->seed_index += n_frames;
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
+        if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
+        if (c->dirty) {  // mod.rs:169-195
+            int r = mi355pt_clear(c);
+            if (r != MI355PT_OK) return r;
+        }
+        if (n_frames == 0) return MI355PT_OK;
+        std::vector<uint32_t> own;
+        if (!seeds) {
+            own.resize(n_frames);
+            for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
+            seeds = own.data();
+        }
+        gpu::RenderConfig cfg;
+        cfg.samples = c->settings.samples;
+        cfg.depth = c->settings.depth;
+        cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
+        cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
+        std::string err;
+        if (!gpu::enqueue(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        c->frames += (int32_t)n_frames;
+        c->seed_index += n_frames;
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_render_static(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
-    if (!c) return MI355PT_ERR_ARG;
-    if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
-    if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
-    if (n_frames > gpu::STATIC_MAX_FRAMES)
-        return fail(c, MI355PT_ERR_ARG, "render_static: at most " + std::to_string(gpu::STATIC_MAX_FRAMES) + " frames per call");
-    SETTLE_OR_RETURN(c);
-    if (c->dirty) {  // mod.rs:169-195; the clear is a fill kernel and two memsets, no allocation
-        int r = mi355pt_clear(c);
-        if (r != MI355PT_OK) return r;
-    }
-    if (n_frames == 0) return MI355PT_OK;
-    uint32_t own[gpu::STATIC_MAX_FRAMES];
-    if (!seeds) {
-        for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
-        seeds = own;
-    }
-    gpu::RenderConfig cfg;
-    cfg.samples = c->settings.samples;
-    cfg.depth = c->settings.depth;
-    cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
-    cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
-    std::string err;
-    if (!gpu::render_static(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) {
-        const bool arg = err.rfind("render_static:", 0) == 0;  // a size the workspace cannot hold
-        return fail(c, arg ? MI355PT_ERR_ARG : MI355PT_ERR_DEVICE, err);
-    }
-    c->frames += (int32_t)n_frames;
-    c->seed_index += n_frames;
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
+        if (!c->have_camera) return fail(c, MI355PT_ERR_STATE, "render: no camera (call set_camera or set_camera_config)");
+        if (n_frames > gpu::STATIC_MAX_FRAMES)
+            return fail(c, MI355PT_ERR_ARG, "render_static: at most " + std::to_string(gpu::STATIC_MAX_FRAMES) + " frames per call");
+        SETTLE_OR_RETURN(c);
+        if (c->dirty) {  // mod.rs:169-195; the clear is a fill kernel and two memsets, no allocation
+            int r = mi355pt_clear(c);
+            if (r != MI355PT_OK) return r;
+        }
+        if (n_frames == 0) return MI355PT_OK;
+        uint32_t own[gpu::STATIC_MAX_FRAMES];
+        if (!seeds) {
+            for (uint32_t f = 0; f < n_frames; f++) own[f] = frame_seed(c->desc.base_seed, c->seed_index + f);
+            seeds = own;
+        }
+        gpu::RenderConfig cfg;
+        cfg.samples = c->settings.samples;
+        cfg.depth = c->settings.depth;
+        cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
+        cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
+        std::string err;
+        if (!gpu::render_static(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) {
+            const bool arg = err.rfind("render_static:", 0) == 0;  // a size the workspace cannot hold
+            return fail(c, arg ? MI355PT_ERR_ARG : MI355PT_ERR_DEVICE, err);
+        }
+        c->frames += (int32_t)n_frames;
+        c->seed_index += n_frames;
+        return MI355PT_OK;
+    });
 }
 
 void mi355pt_partition_frames(uint32_t total, uint32_t parts, uint32_t part, uint32_t* first, uint32_t* count) {
@@ -313,49 +342,55 @@ void mi355pt_partition_frames(uint32_t total, uint32_t parts, uint32_t part, uin
 }
 
 int mi355pt_reduce(mi355pt_ctx* const* ctxs, size_t n, size_t root) {
-    if (!ctxs || n == 0 || root >= n) return fail(nullptr, MI355PT_ERR_ARG, "reduce: bad arguments");
-    for (size_t i = 0; i < n; i++)
-        if (!ctxs[i]) return fail(nullptr, MI355PT_ERR_ARG, "reduce: null context");
-    mi355pt_ctx* r = ctxs[root];
-    std::vector<gpu::Device*> devs(n);
-    int64_t frames = 0;
-    for (size_t i = 0; i < n; i++) {
-        int rc = settle(ctxs[i]);
-        if (rc != MI355PT_OK) return i == root ? rc : fail(r, rc, "reduce: context " + std::to_string(i) + ": " + ctxs[i]->error);
-        if (ctxs[i]->dirty || ctxs[i]->frames < 0)
-            return fail(r, MI355PT_ERR_STATE, "reduce: context " + std::to_string(i) + " holds no rendered frames (its accumulator is due to be cleared)");
-        devs[i] = ctxs[i]->dev;
-        frames += ctxs[i]->frames;
-    }
-    std::string err;
-    if (!gpu::reduce_accum(devs.data(), n, root, err)) return fail(r, MI355PT_ERR_DEVICE, err);
-    for (size_t i = 0; i < n; i++) {
-        if (i == root) continue;
-        r->stats.paths += ctxs[i]->stats.paths, r->stats.rays += ctxs[i]->stats.rays;
-        ctxs[i]->dirty = true;  // its accumulator is spent: the next render starts a new accumulation
-    }
-    r->frames = (int32_t)frames;
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!ctxs || n == 0 || root >= n) return fail(nullptr, MI355PT_ERR_ARG, "reduce: bad arguments");
+        for (size_t i = 0; i < n; i++)
+            if (!ctxs[i]) return fail(nullptr, MI355PT_ERR_ARG, "reduce: null context");
+        mi355pt_ctx* r = ctxs[root];
+        std::vector<gpu::Device*> devs(n);
+        int64_t frames = 0;
+        for (size_t i = 0; i < n; i++) {
+            int rc = settle(ctxs[i]);
+            if (rc != MI355PT_OK) return i == root ? rc : fail(r, rc, "reduce: context " + std::to_string(i) + ": " + ctxs[i]->error);
+            if (ctxs[i]->dirty || ctxs[i]->frames < 0)
+                return fail(r, MI355PT_ERR_STATE, "reduce: context " + std::to_string(i) + " holds no rendered frames (its accumulator is due to be cleared)");
+            devs[i] = ctxs[i]->dev;
+            frames += ctxs[i]->frames;
+        }
+        std::string err;
+        if (!gpu::reduce_accum(devs.data(), n, root, err)) return fail(r, MI355PT_ERR_DEVICE, err);
+        for (size_t i = 0; i < n; i++) {
+            if (i == root) continue;
+            r->stats.paths += ctxs[i]->stats.paths, r->stats.rays += ctxs[i]->stats.rays;
+            ctxs[i]->dirty = true;  // its accumulator is spent: the next render starts a new accumulation
+        }
+        r->frames = (int32_t)frames;
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_reduce_comm(mi355pt_ctx* c, void* nccl_comm, int root_rank, int my_rank, int32_t total_frames) {
-    if (!c || !nccl_comm) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    if (c->dirty || c->frames < 0) return fail(c, MI355PT_ERR_STATE, "reduce: no rendered frames (the accumulator is due to be cleared)");
-    std::string err;
-    if (!gpu::reduce_accum_comm(c->dev, nccl_comm, root_rank, err)) return fail(c, MI355PT_ERR_DEVICE, err);
-    if (my_rank == root_rank) {
-        if (!gpu::set_alpha(c->dev, 1.0f, err)) return fail(c, MI355PT_ERR_DEVICE, err);
-        c->frames = total_frames;
-    } else {
-        c->dirty = true;
-    }
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !nccl_comm) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        if (c->dirty || c->frames < 0) return fail(c, MI355PT_ERR_STATE, "reduce: no rendered frames (the accumulator is due to be cleared)");
+        std::string err;
+        if (!gpu::reduce_accum_comm(c->dev, nccl_comm, root_rank, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        if (my_rank == root_rank) {
+            if (!gpu::set_alpha(c->dev, 1.0f, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+            c->frames = total_frames;
+        } else {
+            c->dirty = true;
+        }
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_wait(mi355pt_ctx* c) {
-    if (!c) return MI355PT_ERR_ARG;
-    return settle(c);
+    return guarded(c, [&]() -> int {
+        if (!c) return MI355PT_ERR_ARG;
+        return settle(c);
+    });
 }
 
 int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
@@ -366,63 +401,73 @@ int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
 int32_t mi355pt_frames(const mi355pt_ctx* c) { return c ? c->frames : -1; }
 
 int mi355pt_read_accum(mi355pt_ctx* c, float* rgba, size_t n_floats) {
-    if (!c || !rgba) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    std::string err;
-    if (!gpu::read_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !rgba) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        std::string err;
+        if (!gpu::read_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_write_accum(mi355pt_ctx* c, const float* rgba, size_t n_floats, int32_t frames) {
-    if (!c || !rgba) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    std::string err;
-    if (!gpu::write_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
-    c->frames = frames;
-    c->dirty = false;
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !rgba) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        std::string err;
+        if (!gpu::write_accum(c->dev, rgba, n_floats, err)) return fail(c, MI355PT_ERR_ARG, err);
+        c->frames = frames;
+        c->dirty = false;
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_to_rgb8(mi355pt_ctx* c, int32_t frames, uint8_t* rgb, size_t n_bytes) {
-    if (!c || !rgb) return MI355PT_ERR_ARG;
-    if (n_bytes != (size_t)c->width * c->height * 3) return fail(c, MI355PT_ERR_ARG, "to_rgb8: n_bytes must be 3 * width * height");
-    if (frames < 1) return fail(c, MI355PT_ERR_ARG, "to_rgb8: frames must be >= 1");
-    SETTLE_OR_RETURN(c);
-    std::vector<float> acc((size_t)c->width * c->height * 4);
-    std::string err;
-    if (!gpu::read_accum(c->dev, acc.data(), acc.size(), err)) return fail(c, MI355PT_ERR_DEVICE, err);
-    postprocess_rgb8(acc.data(), c->width, c->height, frames, rgb);
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !rgb) return MI355PT_ERR_ARG;
+        if (n_bytes != (size_t)c->width * c->height * 3) return fail(c, MI355PT_ERR_ARG, "to_rgb8: n_bytes must be 3 * width * height");
+        if (frames < 1) return fail(c, MI355PT_ERR_ARG, "to_rgb8: frames must be >= 1");
+        SETTLE_OR_RETURN(c);
+        std::vector<float> acc((size_t)c->width * c->height * 4);
+        std::string err;
+        if (!gpu::read_accum(c->dev, acc.data(), acc.size(), err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        postprocess_rgb8(acc.data(), c->width, c->height, frames, rgb);
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_save_png(mi355pt_ctx* c, int32_t frames, const char* path) {
-    if (!c || !path) return MI355PT_ERR_ARG;
-    std::vector<uint8_t> rgb((size_t)c->width * c->height * 3);
-    int r = mi355pt_to_rgb8(c, frames, rgb.data(), rgb.size());
-    if (r != MI355PT_OK) return r;
-    std::string err;
-    if (!write_png_rgb8(path, rgb.data(), c->width, c->height, err)) return fail(c, MI355PT_ERR_IO, err);
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !path) return MI355PT_ERR_ARG;
+        std::vector<uint8_t> rgb((size_t)c->width * c->height * 3);
+        int r = mi355pt_to_rgb8(c, frames, rgb.data(), rgb.size());
+        if (r != MI355PT_OK) return r;
+        std::string err;
+        if (!write_png_rgb8(path, rgb.data(), c->width, c->height, err)) return fail(c, MI355PT_ERR_IO, err);
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
-    if (!c || !out) return MI355PT_ERR_ARG;
-    SETTLE_OR_RETURN(c);
-    memset(out, 0, sizeof *out);
-    out->paths = c->stats.paths, out->rays = c->stats.rays;
-    out->nodes = c->stats.nodes, out->tests = c->stats.tests, out->accepted = c->stats.accepted;
-    for (int k = 0; k < 5; k++) out->bounces[k] = c->stats.bounces[k];
-    for (int k = 0; k < 12; k++) out->phase[k] = c->stats.phase[k];
-    out->render_ms = c->stats.render_ms, out->resolve_ms = c->stats.resolve_ms;
-    out->launches = c->stats.launches;
-    out->bvh_nodes = c->have_scene ? c->layout.n_nodes : 0u;
-    out->bvh_depth = c->have_scene ? c->layout.max_depth : 0u;
-    out->scene_bytes = c->layout.total_bytes;
-    out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
-    out->node_format = c->have_scene ? c->layout.node_half : 0u;
-    out->exchange_on = c->stats.exchange_on ? 1u : 0u;
-    for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
-    return MI355PT_OK;
+    return guarded(c, [&]() -> int {
+        if (!c || !out) return MI355PT_ERR_ARG;
+        SETTLE_OR_RETURN(c);
+        memset(out, 0, sizeof *out);
+        out->paths = c->stats.paths, out->rays = c->stats.rays;
+        out->nodes = c->stats.nodes, out->tests = c->stats.tests, out->accepted = c->stats.accepted;
+        for (int k = 0; k < 5; k++) out->bounces[k] = c->stats.bounces[k];
+        for (int k = 0; k < 12; k++) out->phase[k] = c->stats.phase[k];
+        out->render_ms = c->stats.render_ms, out->resolve_ms = c->stats.resolve_ms;
+        out->launches = c->stats.launches;
+        out->bvh_nodes = c->have_scene ? c->layout.n_nodes : 0u;
+        out->bvh_depth = c->have_scene ? c->layout.max_depth : 0u;
+        out->scene_bytes = c->layout.total_bytes;
+        out->scene_in_lds = c->have_scene && gpu::scene_in_lds(c->dev) ? 1u : 0u;
+        out->node_format = c->have_scene ? c->layout.node_half : 0u;
+        out->exchange_on = c->stats.exchange_on ? 1u : 0u;
+        for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_accum_device_ptr(mi355pt_ctx* c, void** ptr, void** stream) {
@@ -460,45 +505,53 @@ int64_t mi355pt_bvh_build_reference(const void* spheres32, size_t n_spheres, int
 uint32_t mi355pt_frame_seed(uint32_t base_seed, uint32_t frame) { return frame_seed(base_seed, frame); }
 
 int mi355pt_postprocess_rgb8(const float* accum_rgba, uint32_t width, uint32_t height, int32_t frames, uint8_t* rgb) {
-    if (!accum_rgba || !rgb || frames < 1) return MI355PT_ERR_ARG;
-    postprocess_rgb8(accum_rgba, width, height, frames, rgb);
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!accum_rgba || !rgb || frames < 1) return MI355PT_ERR_ARG;
+        postprocess_rgb8(accum_rgba, width, height, frames, rgb);
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_write_png_rgb8(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height) {
-    if (!path || !rgb || !width || !height) return MI355PT_ERR_ARG;
-    std::string err;
-    if (!write_png_rgb8(path, rgb, width, height, err)) {
-        g_create_error = err;
-        return MI355PT_ERR_IO;
-    }
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!path || !rgb || !width || !height) return MI355PT_ERR_ARG;
+        std::string err;
+        if (!write_png_rgb8(path, rgb, width, height, err)) {
+            g_create_error = err;
+            return MI355PT_ERR_IO;
+        }
+        return MI355PT_OK;
+    });
 }
 
 // ---- RON ------------------------------------------------------------------------------------------
 int mi355pt_scene_parse_ron(const char* text, size_t len, mi355pt_scene** out, char* errbuf, size_t errbuf_len) {
-    if (!text || !out) return MI355PT_ERR_ARG;
-    *out = nullptr;
-    std::unique_ptr<mi355pt_scene> s(new (std::nothrow) mi355pt_scene());
-    if (!s) return MI355PT_ERR_NOMEM;
-    std::string err;
-    if (!parse_scene_ron(std::string(text, len), s->scene, err)) {
-        copy_err(err, errbuf, errbuf_len);
-        return MI355PT_ERR_IO;
-    }
-    *out = s.release();
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!text || !out) return MI355PT_ERR_ARG;
+        *out = nullptr;
+        std::unique_ptr<mi355pt_scene> s(new (std::nothrow) mi355pt_scene());
+        if (!s) return MI355PT_ERR_NOMEM;
+        std::string err;
+        if (!parse_scene_ron(std::string(text, len), s->scene, err)) {
+            copy_err(err, errbuf, errbuf_len);
+            return MI355PT_ERR_IO;
+        }
+        *out = s.release();
+        return MI355PT_OK;
+    });
 }
 
 int mi355pt_scene_load_ron(const char* path, mi355pt_scene** out, char* errbuf, size_t errbuf_len) {
-    if (!path || !out) return MI355PT_ERR_ARG;
-    *out = nullptr;
-    std::string text, err;
-    if (!read_file(path, text, err)) {
-        copy_err(err, errbuf, errbuf_len);
-        return MI355PT_ERR_IO;
-    }
-    return mi355pt_scene_parse_ron(text.data(), text.size(), out, errbuf, errbuf_len);
+    return guarded(nullptr, [&]() -> int {
+        if (!path || !out) return MI355PT_ERR_ARG;
+        *out = nullptr;
+        std::string text, err;
+        if (!read_file(path, text, err)) {
+            copy_err(err, errbuf, errbuf_len);
+            return MI355PT_ERR_IO;
+        }
+        return mi355pt_scene_parse_ron(text.data(), text.size(), out, errbuf, errbuf_len);
+    });
 }
 
 mi355pt_scene* mi355pt_scene_default(void) {
@@ -532,25 +585,29 @@ void mi355pt_scene_camera(const mi355pt_scene* s, float out6[6]) {
 }
 
 int mi355pt_set_scene_handle(mi355pt_ctx* c, const mi355pt_scene* s) {
-    if (!c || !s) return MI355PT_ERR_ARG;
-    const Scene& sc = s->scene;
-    int r = mi355pt_set_scene(c, sc.spheres.data(), sc.spheres.size(), sc.lights.data(), sc.lights.size(),
-                              sc.lambertians.data(), sc.lambertians.size(), sc.metals.data(), sc.metals.size(),
-                              sc.glass.data(), sc.glass.size());
-    if (r != MI355PT_OK) return r;
-    return mi355pt_set_camera_config(c, sc.camera.pos, sc.camera.yaw, sc.camera.pitch, sc.camera.vfov);
+    return guarded(c, [&]() -> int {
+        if (!c || !s) return MI355PT_ERR_ARG;
+        const Scene& sc = s->scene;
+        int r = mi355pt_set_scene(c, sc.spheres.data(), sc.spheres.size(), sc.lights.data(), sc.lights.size(),
+                                  sc.lambertians.data(), sc.lambertians.size(), sc.metals.data(), sc.metals.size(),
+                                  sc.glass.data(), sc.glass.size());
+        if (r != MI355PT_OK) return r;
+        return mi355pt_set_camera_config(c, sc.camera.pos, sc.camera.yaw, sc.camera.pitch, sc.camera.vfov);
+    });
 }
 
 int mi355pt_settings_load_ron(const char* path, int32_t* samples, int32_t* depth, char* errbuf, size_t errbuf_len) {
-    if (!path || !samples || !depth) return MI355PT_ERR_ARG;
-    std::string text, err;
-    Settings s;
-    if (!read_file(path, text, err) || !parse_settings_ron(text, s, err)) {
-        copy_err(err, errbuf, errbuf_len);
-        return MI355PT_ERR_IO;
-    }
-    *samples = s.samples, *depth = s.depth;
-    return MI355PT_OK;
+    return guarded(nullptr, [&]() -> int {
+        if (!path || !samples || !depth) return MI355PT_ERR_ARG;
+        std::string text, err;
+        Settings s;
+        if (!read_file(path, text, err) || !parse_settings_ron(text, s, err)) {
+            copy_err(err, errbuf, errbuf_len);
+            return MI355PT_ERR_IO;
+        }
+        *samples = s.samples, *depth = s.depth;
+        return MI355PT_OK;
+    });
 }
 
 }  // extern "C"

@@ -8,6 +8,7 @@
 #include <limits>
 #include <thread>
 #include <queue>
+#include <system_error>
 #include <utility>
 #include <vector>
 
@@ -335,11 +336,16 @@ struct SahBuilder {
         }
         if (fork_levels > 0 && n >= (1u << 16)) {
             std::vector<TmpNode> right_nodes;
-            auto right = std::async(std::launch::async, [&, mid, hi, depth, fork_levels]() {
-                return build(right_nodes, mid, hi, depth + 1, false, fork_levels - 1);
-            });
+            std::future<int32_t> right;
+            try {
+                right = std::async(std::launch::async, [&, mid, hi, depth, fork_levels]() {
+                    return build(right_nodes, mid, hi, depth + 1, false, fork_levels - 1);
+                });
+            } catch (const std::system_error&) {
+                // no thread to be had (a process or thread limit): this subtree is built here; the tree is the same
+            }
             int32_t l = build(tmp, lo, mid, depth + 1, false, fork_levels - 1);
-            int32_t r = right.get();
+            int32_t r = right.valid() ? right.get() : build(right_nodes, mid, hi, depth + 1, false, 0);
             const int32_t shift = (int32_t)tmp.size();
             for (TmpNode& t : right_nodes)
                 if (t.count == 0) t.left += shift, t.right += shift;
