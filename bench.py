@@ -12,6 +12,7 @@ RCCL inside the timed region.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -22,7 +23,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_VALU_TFLOPS = 157.3   # MI355X vector FP32 peak (= the FP32 MFMA peak): 256 CUs x 128 FMA lanes x 2.4 GHz
 PEAK_HBM_GBS = 8000.0
 # rocprofv3 summary of this command (tools/profile.sh): source of roofline.traffic and of the issue-slot figure
-PROFILE = os.path.join("profiles", "r01_v14_final", "pmc_summary.json")
+PROFILE = os.path.join("profiles", "r02_final", "pmc_summary.json")
 # highest sustained vector issue rate measured on MI355X (tools/micro/valu_peak, profiles/r01_micro/valu_peak.txt)
 MEASURED_VALU_ISSUE_PER_SIMD = 9.07e8   # wave-instructions / s / SIMD
 
@@ -51,7 +52,7 @@ def profile_counters(kernel_prefix):
     except Exception:
         return None
     for name, v in d.items():
-        if kernel_prefix in name and "false" in name:
+        if kernel_prefix in name and re.search(r"<\d+, false,", name):   # <SCENE, COUNT = false, lanes, ...>
             return {k: c["avg"] for k, c in v.get("counters_avg_per_dispatch", {}).items()}
     return None
 
