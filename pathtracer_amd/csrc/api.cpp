@@ -478,6 +478,14 @@ int mi355pt_accum_device_ptr(mi355pt_ctx* c, void** ptr, void** stream) {
     return MI355PT_OK;
 }
 
+#ifdef PT_WAVE_END_HIST
+// development builds only: the raw kernel counters
+int mi355pt_debug_counters(mi355pt_ctx* c, uint64_t* out, size_t n) {
+    std::string err;
+    return c && out && gpu::debug_counters(c->dev, reinterpret_cast<unsigned long long*>(out), n, err) ? MI355PT_OK : MI355PT_ERR_DEVICE;
+}
+#endif
+
 // ---- host-side pieces ---------------------------------------------------------------------------
 int mi355pt_camera_build(const float pos[3], float yaw_deg, float pitch_deg, float vfov_deg, float aspect, void* out) {
     if (!pos || !out) return MI355PT_ERR_ARG;

@@ -68,6 +68,8 @@ bool reduce_accum(Device* const* devs, size_t n, size_t root, std::string& err);
 // accumulator is unchanged; on root the alpha channel holds the rank count afterwards (set_alpha puts 1 back).
 bool reduce_accum_comm(Device* d, void* nccl_comm, int root, std::string& err);
 bool set_alpha(Device* d, float alpha, std::string& err);
+// Raw kernel counters (development builds read their histograms here).
+bool debug_counters(Device* d, unsigned long long* out, size_t n, std::string& err);
 bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
 void* accum_device_ptr(Device* d);

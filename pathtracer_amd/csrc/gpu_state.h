@@ -13,6 +13,7 @@
 namespace pt {
 namespace gpu {
 
+constexpr size_t COUNTER_BYTES = 1024;  // 128 kernel counters: 0..31 statistics and watchdog, 32..95 development histograms
 constexpr uint32_t RAY_SLOTS = 64, RAY_SLOT_STRIDE = 16;  // 64 ray counters, 128 bytes apart
 
 // Makes `id` the calling thread's current device for the lifetime of the guard and puts the caller's
@@ -45,10 +46,8 @@ struct Switches {
     bool lockstep = false;      // MI355PT_KERNEL=lockstep: the simple kernel
     uint64_t watchdog_ms = 20000;  // MI355PT_WATCHDOG_MS
     uint32_t thr[6] = {12, 8, 24, 16, 6, 32};  // MI355PT_SCHED: step thresholds node, leaf, -, opaque, glass, restart
-    bool exchange = false;                      // MI355PT_XCHG=1: exchange variant of the scheduled kernel
-    uint32_t pool_min[2] = {48, 32};            // MI355PT_XCHG_MIN: pool sizes from which a restart withdraws
-    uint32_t pool_dep_min[2] = {4, 2};          // MI355PT_XCHG_DEP_MIN: fewest waiting lanes worth a deposit
-    uint32_t xthr[6] = {12, 8, 24, 16, 6, 32}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
+    bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
+    uint32_t xthr[6] = {12, 8, 24, 24, 12, 28}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
 };
 // Results of one launch wait in a frame buffer for the accumulation kernel; it is at most this large (and at
 // most a quarter of the free device memory): 334 frames at 1920x1080, 84 at 3840x2160.

@@ -184,17 +184,23 @@ struct RenderParams {
     // stack_lds_entries in LDS and the rest in stack_spill[block][entry][lane]
     int32_t* stack_spill;
     uint32_t stack_lds_entries, stack_spill_entries;
-    // Exchange variant of pt_render_sched_kernel: LDS offset of the workgroup's two path pools and the pool
-    // size from which a restarting wave withdraws (opaque, glass)
+    // Exchange variant of pt_render_sched_kernel: LDS offset of the workgroup's two path pools (0: not in use)
     uint32_t pool_off;
-    uint32_t pool_min[2];
-    uint32_t pool_dep_min[2];  // fewest waiting lanes worth a deposit
 };
 
 // Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
 // a stack of POOL_CAP records of 16 words, stored as four planes of 16-byte quarters so that consecutive slots
 // hit consecutive banks.  Header: per class a lock word and the entry count.
 constexpr uint32_t POOL_CAP = 64, POOL_HEADER = 64, POOL_BYTES = POOL_HEADER + 2u * POOL_CAP * 64u;
+// A restarting wave takes a batch out of a pool that holds at least POOL_MIN_* paths; a wave parks the lanes it
+// has waiting for a class when they are at least POOL_DEP_MIN_* (and fewer than the class's threshold).
+// Compile-time on purpose: as kernel arguments they would sit in scalar registers through the whole loop.
+#ifndef PT_POOL_TUNING
+#define PT_POOL_TUNING 48, 32, 4, 2
+#endif
+constexpr uint32_t POOL_TUNING[4] = {PT_POOL_TUNING};
+constexpr uint32_t POOL_MIN_OPAQUE = POOL_TUNING[0], POOL_MIN_GLASS = POOL_TUNING[1];
+constexpr uint32_t POOL_DEP_MIN_OPAQUE = POOL_TUNING[2], POOL_DEP_MIN_GLASS = POOL_TUNING[3];
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -441,7 +447,21 @@ __device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32
 #endif
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
-template <int SCENE, bool COUNT, int BLK, bool XCHG = false>
+// The kernel's arguments as they lie in the kernarg segment, for the parts of a kernel that run rarely (the
+// restart step: once per path).  Read through this view at the point of use, their values occupy scalar
+// registers only there; as plain kernel arguments the compiler loads them once and keeps all of them for the
+// whole persistent loop, and at eight waves per SIMD (80 scalar registers) that means spills, each of which is
+// a vector instruction (v_writelane / v_readlane).  The empty asm keeps the compiler from hoisting the loads.
+typedef const __attribute__((address_space(4))) RenderParams* KernargView;
+__device__ __forceinline__ KernargView kernarg_view() {
+    KernargView q = (KernargView)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(q));
+    return q;
+}
+
+// FAST: one sample per path and 12-byte results (what every launch but the occasional cost-measuring one is): the
+// per-path sample sum, sample counter, pixel coordinates and ray count need no registers of their own.
+template <int SCENE, bool COUNT, int BLK, bool XCHG = false, bool FAST = false>
 __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK == 1024 ? 8 : 1, 8))) pt_render_sched_kernel(const RenderParams P) {
     constexpr bool LDS_SCENE = SCENE == SCENE_LDS || SCENE == SCENE_LDS_HALF, HALF = SCENE == SCENE_LDS_HALF;
     extern __shared__ __align__(16) char smem[];
@@ -466,8 +486,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         stack.lds_entries = (int32_t)P.stack_lds_entries;
     }
 
-    const CameraRegs cam = load_camera(P.cam);
-    const float fw = (float)P.width, fh = (float)P.height;
     const uint32_t lane = threadIdx.x & 63u;
 
     PathState ps;
@@ -487,13 +505,24 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     uint32_t ph_exec[PH_COUNT] = {0}, ph_lanes[PH_COUNT] = {0};  // COUNT: wave-level step executions
 
     uint32_t next = 0, end = 0;  // wave-uniform: the wave's chunk of the path queue
-    uint32_t chunk = guided_chunk_units(P.total_units, 0u, P.inv_share, P.chunk_max);
-    if (P.rank_chunk) chunk = min(chunk, (uint32_t)P.rank_chunk[0]);
+    uint32_t chunk;
+    {
+        KernargView Q = kernarg_view();
+        chunk = guided_chunk_units(Q->total_units, 0u, Q->inv_share, Q->chunk_max);
+        if (Q->rank_chunk) chunk = min(chunk, (uint32_t)Q->rank_chunk[0]);
+    }
     bool exhausted = false;
     bool force = false;
 
     // One sample of a path has ended with `radiance`.
     auto finish_sample = [&](V3 radiance) {
+        if constexpr (FAST) {
+            // the same additions as below with the sum still at zero (0 + x keeps x's bits except for -0)
+            float* o = reinterpret_cast<float*>(P.frame_out) + (size_t)out_index * 3u;
+            o[0] = 0.0f + radiance.x, o[1] = 0.0f + radiance.y, o[2] = 0.0f + radiance.z;
+            w.cur = LANE_IDLE;
+            return;
+        }
         final_colour = final_colour + radiance;
         sample_i++;
         w.cur = LANE_NEXT;
@@ -511,8 +540,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             w.cur = LANE_IDLE;
         }
     };
+    uint32_t waiting = 0;  // lanes counted by the last call of wants()
     auto wants = [&](bool mine, int ph) -> bool {
         const uint32_t n = (uint32_t)__popcll(__ballot(mine));
+        waiting = n;
         const bool go = n >= (force ? 1u : P.thr[ph]);  // thresholds are >= 1
         if (COUNT && go) ph_exec[ph]++, ph_lanes[ph] += n;
         return go;
@@ -568,7 +599,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             put(3, __float_as_uint(ps.d.x)), put(4, __float_as_uint(ps.d.y)), put(5, __float_as_uint(ps.d.z));
             put(6, __float_as_uint(ps.colour.x)), put(7, __float_as_uint(ps.colour.y)), put(8, __float_as_uint(ps.colour.z));
             put(9, ps.rng), put(10, (uint32_t)ps.bounce), put(11, __float_as_uint(w.best_t));
-            put(12, (uint32_t)w.best_code), put(13, mbits), put(14, out_index), put(15, rays);
+            put(12, (uint32_t)w.best_code), put(13, mbits), put(14, out_index);
+            if constexpr (!FAST) put(15, rays);
             w.cur = LANE_IDLE;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane's record is written before the count says so
@@ -607,8 +639,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             ps.colour = mk(__uint_as_float(get(6)), __uint_as_float(get(7)), __uint_as_float(get(8)));
             ps.rng = get(9), ps.bounce = (int32_t)get(10);
             w.best_t = __uint_as_float(get(11)), w.best_code = (int32_t)get(12);
-            mbits = get(13), out_index = get(14), rays = get(15);
-            final_colour = mk(0.0f, 0.0f, 0.0f), sample_i = 0;  // one sample per path in this variant
+            mbits = get(13), out_index = get(14);
+            if constexpr (!FAST) rays = get(15), final_colour = mk(0.0f, 0.0f, 0.0f), sample_i = 0;  // one sample per path in this variant
             w.cur = cls ? LANE_GLASS : LANE_OPAQUE;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // every lane has its record before the slots are free again
@@ -676,32 +708,24 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             }
         }
         // ---- restart, first half (exchange variant): close the paths that end here, then fill idle lanes from a
-        // pool that holds enough paths of one scatter class; the scatter steps below then run them
+        // pool that holds enough paths of one scatter class; the scatter steps below then run them (a batch is at
+        // least as large as the class's threshold: the host sees to pool_min >= thr)
         bool do_restart = false;
-        bool took[2] = {false, false};  // a batch came out of that class's pool this round: its scatter step runs now
+        [[maybe_unused]] const bool may_park = !force && !exhausted;  // a wave that has seen the queue empty only takes
         if constexpr (XCHG) {
             do_restart = wants(lane_wants_restart(w.cur), PH_IDLE);
-            const bool free_now = w.cur == LANE_IDLE || w.cur == LANE_EXIT;
-            if (do_restart || (exhausted && __ballot(free_now))) {
+            if (do_restart || (exhausted && __ballot(w.cur == LANE_IDLE || w.cur == LANE_EXIT))) {
                 if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
                 if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
-                // the fuller pool first; a wave that has seen the queue empty takes whatever is left
-                const uint32_t first = pool_count(1) > pool_count(0) ? 1u : 0u;
-#pragma unroll
-                for (uint32_t pass = 0; pass < 2u; pass++) {
-                    const uint32_t cls = pass ? 1u - first : first;
-                    if (withdraw(cls, w.cur == LANE_IDLE || w.cur == LANE_EXIT, exhausted ? 1u : P.pool_min[cls])) ran = took[cls] = true;
-                }
+                // glass first (the class that runs thinnest on its own); with the queue empty whatever is left
+                if (withdraw(1u, w.cur == LANE_IDLE || w.cur == LANE_EXIT, exhausted ? 1u : POOL_MIN_GLASS)) ran = true;
+                if (withdraw(0u, w.cur == LANE_IDLE || w.cur == LANE_EXIT, exhausted ? 1u : POOL_MIN_OPAQUE)) ran = true;
             }
         }
         // ---- lambertian / metal
         bool run_opaque = wants(w.cur == LANE_OPAQUE, PH_OPAQUE);
         if constexpr (XCHG) {
-            if (took[0] && !run_opaque) {
-                run_opaque = true;
-                if (COUNT) ph_exec[PH_OPAQUE]++, ph_lanes[PH_OPAQUE] += (uint32_t)__popcll(__ballot(w.cur == LANE_OPAQUE));
-            }
-            if (!run_opaque && !force && !exhausted && (uint32_t)__popcll(__ballot(w.cur == LANE_OPAQUE)) >= P.pool_dep_min[0]) {
+            if (!run_opaque && may_park && waiting >= POOL_DEP_MIN_OPAQUE) {
                 if (deposit(0u, w.cur == LANE_OPAQUE)) ran = true;
                 else run_opaque = true;  // the pool is full: the waves that empty it are behind
             }
@@ -716,18 +740,14 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     finish_sample(radiance);
                 } else {
                     walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
-                    rays++;
+                    if constexpr (FAST) lane_rays++; else rays++;
                 }
             }
         }
         // ---- glass
         bool run_glass = wants(w.cur == LANE_GLASS, PH_GLASS);
         if constexpr (XCHG) {
-            if (took[1] && !run_glass) {
-                run_glass = true;
-                if (COUNT) ph_exec[PH_GLASS]++, ph_lanes[PH_GLASS] += (uint32_t)__popcll(__ballot(w.cur == LANE_GLASS));
-            }
-            if (!run_glass && !force && !exhausted && (uint32_t)__popcll(__ballot(w.cur == LANE_GLASS)) >= P.pool_dep_min[1]) {
+            if (!run_glass && may_park && waiting >= POOL_DEP_MIN_GLASS) {
                 if (deposit(1u, w.cur == LANE_GLASS)) ran = true;
                 else run_glass = true;
             }
@@ -742,7 +762,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     finish_sample(radiance);
                 } else {
                     walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
-                    rays++;
+                    if constexpr (FAST) lane_rays++; else rays++;
                 }
             }
         }
@@ -756,26 +776,29 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
                 if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
             }
+            KernargView Q = kernarg_view();  // what only this step needs is read here (see kernarg_view)
+            uint32_t pxy_step = 0;
+            uint32_t& pxy_now = FAST ? pxy_step : pxy;  // with one sample per path a lane gets its camera ray in this very step
             unsigned long long m = __ballot(w.cur == LANE_IDLE);
             while (m) {
                 if (next == end) {
                     if (exhausted) break;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(P.work_counter, chunk);
+                    if (lane == 0) base = atomicAdd(Q->work_counter, chunk);
                     base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);  // lane 0 is active here: the step is entered by the whole wave
-                    if (base >= P.total_units) {
+                    if (base >= Q->total_units) {
                         exhausted = true;
                         break;
                     }
                     next = base * 64u;
-                    end = min(base + chunk, P.total_units) * 64u;
+                    end = min(base + chunk, Q->total_units) * 64u;
                     {
                         const uint32_t taken_to = base + chunk;
-                        chunk = guided_chunk_units(P.total_units, taken_to, P.inv_share, P.chunk_max);
-                        if (P.rank_chunk && taken_to < P.total_units) {
+                        chunk = guided_chunk_units(Q->total_units, taken_to, Q->inv_share, Q->chunk_max);
+                        if (Q->rank_chunk && taken_to < Q->total_units) {
                             // about where the queue will stand at this wave's next visit
-                            const uint32_t r = min(P.tiles_per_frame - 1u, (uint32_t)((float)taken_to * P.inv_n_frames));
-                            chunk = min(chunk, (uint32_t)P.rank_chunk[r]);
+                            const uint32_t r = min(Q->tiles_per_frame - 1u, (uint32_t)((float)taken_to * Q->inv_n_frames));
+                            chunk = min(chunk, (uint32_t)Q->rank_chunk[r]);
                         }
                     }
                 }
@@ -785,27 +808,25 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     const uint32_t pid = next + rank;
                     const uint32_t unit = pid >> 6, slot = pid & 63u;
                     uint32_t frame, tile, tx, ty;
-                    if (P.small_ids) {  // uniform: every id below 2^24, float-reciprocal division
-                        divmod24(unit, P.n_frames, P.inv_n_frames, tile, frame);
+                    if (Q->small_ids) {  // uniform: every id below 2^24, float-reciprocal division
+                        divmod24(unit, Q->n_frames, Q->inv_n_frames, tile, frame);
                     } else {
-                        tile = unit / P.n_frames, frame = unit - tile * P.n_frames;
+                        tile = unit / Q->n_frames, frame = unit - tile * Q->n_frames;
                     }
-                    const uint32_t result_index = (frame * P.tiles_per_frame + tile) * 64u + slot;
-                    if (P.tile_perm) tile = P.tile_perm[tile];
-                    if (P.small_ids) {
-                        divmod24(tile, P.tiles_x, P.inv_tiles_x, ty, tx);
+                    const uint32_t result_index = (frame * Q->tiles_per_frame + tile) * 64u + slot;
+                    if (Q->tile_perm) tile = Q->tile_perm[tile];
+                    if (Q->small_ids) {
+                        divmod24(tile, Q->tiles_x, Q->inv_tiles_x, ty, tx);
                     } else {
-                        ty = tile / P.tiles_x, tx = tile - ty * P.tiles_x;
+                        ty = tile / Q->tiles_x, tx = tile - ty * Q->tiles_x;
                     }
                     const uint32_t px = tx * 8u + (slot & 7u), py = ty * 8u + (slot >> 3);
-                    if (px < P.width && py < P.height) {
-                        const uint32_t pix = py * P.width + px;
-                        ps.rng = pixel_seed(P.seeds[frame], P.pixel_hash[pix]);
+                    if (px < Q->width && py < Q->height) {
+                        const uint32_t pix = py * Q->width + px;
+                        ps.rng = pixel_seed(Q->seeds[frame], Q->pixel_hash[pix]);
                         out_index = result_index;
-                        pxy = px | (py << 16);
-                        final_colour = mk(0.0f, 0.0f, 0.0f);
-                        sample_i = 0;
-                        rays = 0;
+                        pxy_now = px | (py << 16);
+                        if constexpr (!FAST) final_colour = mk(0.0f, 0.0f, 0.0f), sample_i = 0, rays = 0;
                         w.cur = LANE_NEXT;
                     }
                 }
@@ -814,12 +835,14 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             }
             if (w.cur == LANE_IDLE) w.cur = LANE_EXIT;  // the queue is empty: this lane is finished
             if (w.cur == LANE_NEXT) {
-                ps.d = camera_dir(cam, pxy & 0xffffu, pxy >> 16, fw, fh, ps.rng);
+                const CameraRegs cam = {mk(Q->cam.pos[0], Q->cam.pos[1], Q->cam.pos[2]), mk(Q->cam.horizontal[0], Q->cam.horizontal[1], Q->cam.horizontal[2]),
+                                        mk(Q->cam.vertical[0], Q->cam.vertical[1], Q->cam.vertical[2]), mk(Q->cam.center[0], Q->cam.center[1], Q->cam.center[2])};
+                ps.d = camera_dir(cam, pxy_now & 0xffffu, pxy_now >> 16, (float)Q->width, (float)Q->height, ps.rng);
                 ps.o = cam.pos;
                 ps.colour = mk(1.0f, 1.0f, 1.0f);
                 ps.bounce = 0;
                 walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
-                rays++;
+                if constexpr (FAST) lane_rays++; else rays++;
             }
         }
         if (!ran) {
@@ -839,6 +862,11 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     }
 
     flush_rays(P, lane_rays);
+#ifdef PT_WAVE_END_HIST
+    // development build: when the waves end, as a histogram over the device's 100 MHz clock (buckets of
+    // 2^PT_WAVE_END_HIST ticks, modulo 64): the shape of a launch's tail
+    if (lane == 0) atomicAdd(&P.counters[32 + ((__builtin_amdgcn_s_memrealtime() >> PT_WAVE_END_HIST) & 63u)], 1ull);
+#endif
     if (COUNT) {
         unsigned long long v[8] = {cnt.nodes,     cnt.tests,     cnt.accepted,  bounce_cnt[0],
                                    bounce_cnt[1], bounce_cnt[2], bounce_cnt[3], bounce_cnt[4]};
@@ -983,15 +1011,7 @@ static void read_switches(Switches& s) {
     if (const char* e = getenv("MI355PT_CHUNK_RAYS")) s.chunk_rays = std::max(64.0f, (float)atof(e));
     if (const char* e = getenv("MI355PT_KERNEL")) s.lockstep = strcmp(e, "lockstep") == 0;
     s.watchdog_ms = (uint64_t)std::max(1l, env_long("MI355PT_WATCHDOG_MS", 20000));
-    s.exchange = env_long("MI355PT_XCHG", 0) != 0;
-    if (const char* e = getenv("MI355PT_XCHG_MIN")) {
-        unsigned a, b;
-        if (sscanf(e, "%u,%u", &a, &b) == 2) s.pool_min[0] = std::min(std::max(a, 1u), POOL_CAP), s.pool_min[1] = std::min(std::max(b, 1u), POOL_CAP);
-    }
-    if (const char* e = getenv("MI355PT_XCHG_DEP_MIN")) {
-        unsigned a, b;
-        if (sscanf(e, "%u,%u", &a, &b) == 2) s.pool_dep_min[0] = std::max(a, 1u), s.pool_dep_min[1] = std::max(b, 1u);
-    }
+    s.exchange = env_long("MI355PT_XCHG", 1) != 0;
     if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -1069,13 +1089,13 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
         }
         d->own_stream = true;
     }
-    if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, 256) != hipSuccess ||
+    if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, COUNTER_BYTES) != hipSuccess ||
         hipMalloc(&d->ray_slots, RAY_SLOTS * RAY_SLOT_STRIDE * 8) != hipSuccess) {
         destroy(d);
         err = "hipMalloc failed";
         return false;
     }
-    (void)hipMemset(d->counters, 0, 256);
+    (void)hipMemset(d->counters, 0, COUNTER_BYTES);
     (void)hipMemset(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8);
     if (!static_ws_address(device_id, &d->static_ws, err)) {
         destroy(d);
@@ -1202,7 +1222,7 @@ bool clear(Device* d, std::string& err) {
     hipLaunchKernelGGL(pt_fill_kernel, dim3((d->n_pix + 255) / 256), dim3(256), 0, d->stream, d->accum, d->n_pix,
                        v);
     PT_HIP(hipGetLastError());
-    PT_HIP(hipMemsetAsync(d->counters, 0, 256, d->stream));
+    PT_HIP(hipMemsetAsync(d->counters, 0, COUNTER_BYTES, d->stream));
     PT_HIP(hipMemsetAsync(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8, d->stream));
     PT_SYNC_ALL(d);
     return true;
@@ -1233,8 +1253,15 @@ bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err
 template <int SCENE, bool COUNT, int BLK>
 static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, bool lockstep, std::string& err) {
     auto kern = lockstep ? pt_render_kernel<SCENE, COUNT, BLK> : pt_render_sched_kernel<SCENE, COUNT, BLK>;
-    if constexpr (SCENE == SCENE_LDS && BLK == 1024) {
-        if (P.pool_off && !lockstep) kern = pt_render_sched_kernel<SCENE, COUNT, BLK, true>;  // exchange variant
+    const bool fast = !lockstep && !COUNT && P.samples == 1 && P.compact;
+    if constexpr (!COUNT) {
+        if (fast) kern = pt_render_sched_kernel<SCENE, false, BLK, false, true>;
+    }
+    if constexpr (SCENE == SCENE_LDS && BLK == 1024) {  // exchange variant
+        if (P.pool_off && !lockstep) kern = pt_render_sched_kernel<SCENE, COUNT, BLK, true>;
+        if constexpr (!COUNT) {
+            if (P.pool_off && fast) kern = pt_render_sched_kernel<SCENE, false, BLK, true, true>;
+        }
     }
     if (lds_bytes > 48u * 1024u)
         PT_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1457,13 +1484,14 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         lds_bytes = P.scene_lds_bytes + stack_bytes(d->layout, block);
         // Exchange variant (paths waiting for a scatter step move between the waves of a workgroup through two
         // pools in LDS): one sample per path, float nodes, 1024 lanes, and the pools must not cost a workgroup per CU.
-        if (sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 && !d->layout.node_half &&
+        // Scenes of a handful of spheres gain nothing from it (scene2 / scene3: 1 % slower), scene1's 176 nodes 2.4 %.
+        if (sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 && !d->layout.node_half && d->layout.n_nodes >= 32u &&
             lds_cu / (lds_bytes + POOL_BYTES) >= lds_cu / lds_bytes) {
             P.pool_off = (lds_bytes + 15u) & ~15u;
             lds_bytes = P.pool_off + POOL_BYTES;
-            P.pool_min[0] = sw.pool_min[0], P.pool_min[1] = sw.pool_min[1];
-            P.pool_dep_min[0] = sw.pool_dep_min[0], P.pool_dep_min[1] = sw.pool_dep_min[1];
             for (int k = 0; k < 6; k++) P.thr[k] = sw.xthr[k];
+            P.thr[PH_OPAQUE] = std::min(P.thr[PH_OPAQUE], POOL_MIN_OPAQUE);  // a batch out of a pool runs at once
+            P.thr[PH_GLASS] = std::min(P.thr[PH_GLASS], POOL_MIN_GLASS);
         }
     } else {
         // Scene in global memory.  LDS holds, per workgroup, the first stack entries of every lane and
@@ -1785,6 +1813,13 @@ bool reduce_accum(Device* const* devs, size_t n, size_t root, std::string& err) 
         DeviceGuard guard(kv.first);
         PT_HIP(hipStreamSynchronize(kv.second->stream));
     }
+    return true;
+}
+
+bool debug_counters(Device* d, unsigned long long* out, size_t n, std::string& err) {
+    DeviceGuard guard(d->id);
+    PT_HIP(hipStreamSynchronize(d->stream));
+    PT_HIP(hipMemcpy(out, d->counters, std::min(n * 8, COUNTER_BYTES), hipMemcpyDeviceToHost));
     return true;
 }
 

@@ -224,9 +224,8 @@ def test_exchange_variant_is_bit_identical(pa, orc, monkeypatch):
     ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=8)
     monkeypatch.setenv("MI355PT_XCHG", "1")
     monkeypatch.setenv("MI355PT_BLOCK", "1024")
-    for mins, dep in (("48,32", "4,2"), ("2,2", "1,1"), ("64,64", "1,1")):   # defaults; constant traffic; full batches only
-        monkeypatch.setenv("MI355PT_XCHG_MIN", mins)
-        monkeypatch.setenv("MI355PT_XCHG_DEP_MIN", dep)
+    for thr in ("12,8,24,16,6,32", "12,8,24,65,65,32", "20,4,24,40,20,16"):   # defaults; everything thin is parked; odd
+        monkeypatch.setenv("MI355PT_XCHG_SCHED", thr)
         with pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=pa.FLAG_COUNT) as r:
             r.render(seeds=seeds)
             s = r.stats()
