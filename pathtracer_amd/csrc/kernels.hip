@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     }
     bool exhausted = false;
     bool force = false;
+#define PT_THR(ph) (force ? 1u : P.thr[ph])
 
     // One sample of a path has ended with `radiance`.
     auto finish_sample = [&](V3 radiance) {
@@ -544,7 +545,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     auto wants = [&](bool mine, int ph) -> bool {
         const uint32_t n = (uint32_t)__popcll(__ballot(mine));
         waiting = n;
-        const bool go = n >= (force ? 1u : P.thr[ph]);  // thresholds are >= 1
+        const bool go = n >= PT_THR(ph);  // thresholds are >= 1
         if (COUNT && go) ph_exec[ph]++, ph_lanes[ph] += n;
         return go;
     };
@@ -670,7 +671,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     }
                 }
                 const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_node(w.cur)));
-                if (n < (force ? 1u : P.thr[PH_NODE])) break;  // a forced round drains the state
+                if (n < PT_THR(PH_NODE)) break;  // a forced round drains the state
                 if (COUNT) ph_exec[PH_NODE]++, ph_lanes[PH_NODE] += n;
             }
         }
@@ -685,7 +686,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 for (int twice = 0; twice < PT_LEAF_UNROLL; twice++)
                     if (walk_is_leaf(w.cur)) walk_leaf_one<Mem, Stack, COUNT>(mem, P.L, stack, w, ps.o, ps.d, cnt);
                 const uint32_t n = (uint32_t)__popcll(__ballot(walk_is_leaf(w.cur)));
-                if (n < (force ? 1u : P.thr[PH_LEAF])) break;
+                if (n < PT_THR(PH_LEAF)) break;
                 if (COUNT) ph_exec[PH_LEAF]++, ph_lanes[PH_LEAF] += n;
             }
         }
@@ -1606,9 +1607,11 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         P.seeds = dev_seeds + f0;
         // The tile costs are measured on the first launch that is long enough to be representative after the
-        // camera or the settings changed, and again every 16th launch; measuring needs the ray count per path
-        // (16-byte results), all other launches write and re-read 12 bytes per path.
-        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 15u);
+        // camera or the settings changed, and again every 64th launch (they are a property of scene and camera;
+        // the refresh only guards against a first measurement on an unusually short launch); measuring needs
+        // the ray count per path (16-byte results, the kernel's general instance: 10-20 % slower), all other
+        // launches write and re-read 12 bytes per path.
+        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 63u);
         P.compact = measure ? 0u : 1u;
         P.ray_slots = d->ray_slots;
         PT_HIP(hipMemsetAsync(P.work_counter, 0, 4, d->stream));

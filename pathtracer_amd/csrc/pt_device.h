@@ -397,18 +397,18 @@ PT_FN void walk_node(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w
         c0 = (int32_t)ch.x, c1 = (int32_t)ch.y;
     }
     if (COUNT) cnt.nodes++;
+    // Two independent conditional regions (both hit: push one; none hit: pop) around a select, instead of a
+    // four-way if / else chain: the same values with a third fewer exec-mask instructions, and the scalar unit
+    // shares the bound of this loop (scene1, 256 frames: 17.73 -> 17.54 ms).  The same treatment of the sphere
+    // test's nested acceptance was measured 0.4 % slower and is not applied.
+    w.cur = h0 ? c0 : c1;
     if (h0 && h1) {
         bool swap = t1 < t0;
         stack.push(w.sp, swap ? c0 : c1);
         w.sp++;
         w.cur = swap ? c1 : c0;
-    } else if (h0) {
-        w.cur = c0;
-    } else if (h1) {
-        w.cur = c1;
-    } else {
-        walk_pop(w, stack);
     }
+    if (!(h0 || h1)) walk_pop(w, stack);
 }
 
 // The reference's own box test (compute.wgsl:85-96), operation for operation: IEEE divisions by the
