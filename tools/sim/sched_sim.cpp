@@ -587,16 +587,18 @@ int main(int argc, char** argv) {
         double best = 1e30;
         if (const char* e = getenv("SIM_XCOST")) cost[K_RETIRE] *= atof(e), cost[K_REFILL] *= atof(e);
         const int cap_env = getenv("SIM_CAP") ? atoi(getenv("SIM_CAP")) : 128;
-        for (int nthr : {12, 16}) for (int lthr : {8}) for (int othr : {32, 65}) for (int gthr : {65})
+        const bool few = getenv("SIM_FEW") != nullptr;
+        for (int nthr : {12, 16}) for (int lthr : {8}) for (int othr : {24, 32, 65}) for (int gthr : {12, 65})
             for (int rthr : {24, 32}) for (int wo : {32, 48, 64}) for (int wg : {16, 32, 64}) for (int cap : {cap_env}) {
+                if (few && !(nthr == 12 && rthr == 32 && wo == 48 && wg == 32 && ((othr == 24 && gthr == 12) || (othr == 65 && gthr == 65)))) continue;
                 GroupCfg g;
                 g.thr[0] = nthr, g.thr[1] = lthr, g.thr[2] = othr, g.thr[3] = gthr, g.thr[4] = rthr;
                 g.wmin[0] = std::min(wo, cap), g.wmin[1] = std::min(wg, cap), g.cap[0] = g.cap[1] = cap;
                 Tally tl;
                 double mp = 0;
                 for (size_t f = 0; f < paths.size(); f += per_group) run_group(paths, f, std::min(paths.size(), f + per_group), g, tl, &mp);
-                if (tl.total() < best) {
-                    best = tl.total();
+                if (tl.total() < best || few) {
+                    best = std::min(best, tl.total());
                     run_cfg(g, "");
                 }
             }
