@@ -408,6 +408,31 @@ def test_ten_million_spheres_reference_walk(pa, orc):
     assert bits_equal(ref, acc_r) and gs_r["rays"] == st["rays"]
 
 
+def test_watchdog_leaves_the_accumulator_as_it_was(pa, monkeypatch):
+    # A launch whose waves stop finishing paths for longer than the watchdog allows ends with an error, and the
+    # accumulation kernel adds nothing of it: the accumulator still holds exactly the launches that completed.
+    # Provoked with a 1 ms watchdog on the slow fidelity mode (the reference's z-only tree over 300 k spheres:
+    # tens of thousands of node visits per ray).
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(300_000)
+    small = pa.load_ron_scene(os.path.join(FIXTURES, "scene2.ron"))
+    monkeypatch.setenv("MI355PT_WATCHDOG_MS", "1")
+    with pa.Renderer(small, pa.Settings(1, 50), 96, 54) as r:
+        r.render(seeds=[3, 4])                       # quick paths: the watchdog stays quiet
+        before = r.read_accum()
+    with pa.Renderer(sc, pa.Settings(1, 50), 96, 54, bvh_mode=pa.BVH_REFERENCE) as r:
+        r.clear()
+        cleared = r.read_accum()
+        with pytest.raises(pa.Mi355ptError, match="watchdog"):
+            r.render(seeds=[1])
+        assert bits_equal(cleared, r.read_accum())   # nothing of the abandoned launch was added
+        with pytest.raises(pa.Mi355ptError, match="watchdog"):
+            r.render(seeds=[2])                      # reported per launch, not once and for all
+        assert bits_equal(cleared, r.read_accum())
+        assert r.stats()["launches"] >= 2
+    assert np.all(before[..., 3] == 1.0)
+
+
 def test_validation_errors(pa):
     sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene2.ron"))
     bad = pa.load_ron_scene(os.path.join(FIXTURES, "scene2.ron"))
