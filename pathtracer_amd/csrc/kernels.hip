@@ -1455,9 +1455,11 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     P.inv_tiles_x = 1.0f / (float)tiles_x;
     for (int k = 0; k < 6; k++) P.thr[k] = sw.thr[k];
     P.chunk_max = sw.chunk ? sw.chunk : (d->scene_in_lds ? 32u : 4u);
-    // Short launches (fewer than about a hundred 64-path units per resident wave: below 32 frames at 1920x1080)
-    // are a few per cent faster with the smaller workgroups; long ones 7 % faster with 1024 lanes at 8 waves per SIMD.
-    const bool long_launch = (uint64_t)std::min(n_frames, batch) * tiles >= 96ull * 32ull * (uint64_t)d->prop.multiProcessorCount;
+    // Short launches (fewer than about 56 64-path units per resident wave: below 15 frames at 1920x1080) are a
+    // few per cent faster with the smaller workgroups; longer ones with 1024 lanes at 8 waves per SIMD (measured
+    // at 1920x1080: 8 frames 1.15 ms with 512 lanes against 1.23 with 1024; 16 frames 1.75 / 1.74; 24 frames
+    // 2.39 / 2.26; 32 frames 3.03 / 2.78; 256 frames 7 % apart).
+    const bool long_launch = (uint64_t)std::min(n_frames, batch) * tiles >= 56ull * 32ull * (uint64_t)d->prop.multiProcessorCount;
     const bool in_lds = d->scene_in_lds;
     const int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
                            : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
