@@ -577,7 +577,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
     };
-    typedef uint32_t xw4 __attribute__((ext_vector_type(4)));
     // Parks the paths of the lanes with `mine` (all in scatter class `cls`); false when the pool has no room.
     auto deposit = [&](uint32_t cls, bool mine) -> bool {
         const unsigned long long m = __ballot(mine);
