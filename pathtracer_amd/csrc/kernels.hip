@@ -520,7 +520,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         if constexpr (FAST) {
             // the same additions as below with the sum still at zero (0 + x keeps x's bits except for -0)
             float* o = reinterpret_cast<float*>(P.frame_out) + (size_t)out_index * 3u;
-            o[0] = 0.0f + radiance.x, o[1] = 0.0f + radiance.y, o[2] = 0.0f + radiance.z;
+            // written once, read once by the accumulation kernel: streaming stores (accumulation 1.10 -> 1.04 ms per
+            // 256 frames at 1920x1080)
+            __builtin_nontemporal_store(0.0f + radiance.x, o), __builtin_nontemporal_store(0.0f + radiance.y, o + 1),
+                __builtin_nontemporal_store(0.0f + radiance.z, o + 2);
             w.cur = LANE_IDLE;
             return;
         }
@@ -918,7 +921,20 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
             if (compact) {  // 12-byte results; the path kernel has counted the rays
                 const float* c = reinterpret_cast<const float*>(results) + ((size_t)rank * 64u + slot) * 3u;
                 const size_t stride = frame_stride * 3u;
-                for (uint32_t f = 0; f < n_frames; f++) {
+                // the sums are sequential by definition, the fetches are not: eight frames' results are requested
+                // before the first is added (one fetch at a time leaves a wave idle for a memory latency per frame)
+                uint32_t f = 0;
+                for (; f + 8u <= n_frames; f += 8u) {
+                    float v[8][3];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; k++) {
+                        const float* s = c + (size_t)(f + k) * stride;
+                        v[k][0] = __builtin_nontemporal_load(s), v[k][1] = __builtin_nontemporal_load(s + 1), v[k][2] = __builtin_nontemporal_load(s + 2);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; k++) a.x += v[k][0], a.y += v[k][1], a.z += v[k][2], a.w += 0.0f;
+                }
+                for (; f < n_frames; f++) {
                     const float* s = c + (size_t)f * stride;
                     a.x += s[0];
                     a.y += s[1];
