@@ -1433,6 +1433,12 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     }
     batch = std::min<uint32_t>(batch, std::max<uint32_t>(1u, (0xffffffffu / 64u) / tiles));
     batch = std::min(batch, n_frames);
+    // equal launches rather than full ones and a short rest (256 frames at 84 per launch: 4 x 64, not 3 x 84 + 4)
+    auto balanced = [](uint32_t n, uint32_t per_launch) {
+        const uint32_t launches = (n + per_launch - 1u) / per_launch;
+        return (n + launches - 1u) / launches;
+    };
+    if (batch) batch = balanced(n_frames, batch);
     size_t need = (size_t)batch * tiles * 64u;  // whole tiles: [frame][tile rank][64 slots]
     if (!fixed && need > d->frame_cap) {
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
@@ -1571,6 +1577,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         }
         frame_buf = static_cast<char*>(fixed->frame_buf) + spill_bytes;
         batch = (uint32_t)std::min<size_t>({(size_t)batch, room / per_frame, (size_t)n_frames});
+        batch = balanced(n_frames, batch);
     }
 
     // From here on work is queued: whatever fails, finish() has to run before the buffers are touched again.
