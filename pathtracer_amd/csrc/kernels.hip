@@ -1028,6 +1028,7 @@ static void read_switches(Switches& s) {
     if (const char* e = getenv("MI355PT_KERNEL")) s.lockstep = strcmp(e, "lockstep") == 0;
     s.watchdog_ms = (uint64_t)std::max(1l, env_long("MI355PT_WATCHDOG_MS", 20000));
     s.exchange = env_long("MI355PT_XCHG", 1) != 0;
+    s.exchange_global = env_long("MI355PT_XCHG_GLOBAL", 1) != 0;
     if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -1273,7 +1274,7 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
     if constexpr (!COUNT) {
         if (fast) kern = pt_render_sched_kernel<SCENE, false, BLK, false, true>;
     }
-    if constexpr (SCENE == SCENE_LDS && BLK == 1024) {  // exchange variant
+    if constexpr ((SCENE == SCENE_LDS || SCENE == SCENE_GLOBAL) && BLK == 1024) {  // exchange variant
         if (P.pool_off && !lockstep) kern = pt_render_sched_kernel<SCENE, COUNT, BLK, true>;
         if constexpr (!COUNT) {
             if (P.pool_off && fast) kern = pt_render_sched_kernel<SCENE, false, BLK, true, true>;
@@ -1539,6 +1540,17 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         cache = std::max<long>(cache, 0) / 64 * 64;
         P.scene_lds_bytes = (d->layout.off_nodes == 0) ? (uint32_t)cache : 0u;
         lds_bytes = P.scene_lds_bytes + stack_lds;
+        // Exchange variant, as for scenes in LDS (1 M spheres at 3840x2160, 32 frames: 28.5 -> 27.0 ms; 100 k spheres
+        // 24.9 -> 23.6); the pools come out of the node prefix.
+        if (sw.exchange_global && sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 && scene_mode == SCENE_GLOBAL) {
+            if (P.scene_lds_bytes >= POOL_BYTES + 64u) P.scene_lds_bytes -= (POOL_BYTES + 63u) / 64u * 64u;
+            lds_bytes = P.scene_lds_bytes + stack_lds;
+            P.pool_off = (lds_bytes + 15u) & ~15u;
+            lds_bytes = P.pool_off + POOL_BYTES;
+            for (int k = 0; k < 6; k++) P.thr[k] = sw.xthr[k];
+            P.thr[PH_OPAQUE] = std::min(P.thr[PH_OPAQUE], POOL_MIN_OPAQUE);
+            P.thr[PH_GLASS] = std::min(P.thr[PH_GLASS], POOL_MIN_GLASS);
+        }
         const size_t need_spill = (size_t)d->prop.multiProcessorCount * (2048u / block) * P.stack_spill_entries * block;
         if (fixed) {
             if (need_spill > fixed->spill_entries) {

@@ -216,8 +216,8 @@ def test_frame_order_and_batching_do_not_change_bits(pa, monkeypatch):
 
 
 def test_exchange_variant_is_bit_identical(pa, orc, monkeypatch):
-    # MI355PT_XCHG=1 runs the path kernel variant whose waves trade paths that wait for a scatter step through
-    # two pools in LDS (a measured experiment, off by default).  Which wave scatters a path must not change a bit.
+    # The path kernel variant whose waves trade paths that wait for a scatter step through two pools in LDS (the
+    # default for long launches; forced here).  Which wave scatters a path must not change a bit.
     path = os.path.join(FIXTURES, "scene1.ron")
     sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
     W, H, seeds = 200, 112, [7, 8, 9, 10, 11]
@@ -237,6 +237,35 @@ def test_exchange_variant_is_bit_identical(pa, orc, monkeypatch):
     with pa.Renderer(sc, pa.Settings(3, 50), W, H) as r:     # several samples per path: the variant steps aside
         r.render(seeds=seeds[:1])
         assert r.stats()["exchange_on"] == 0
+
+
+def test_exchange_variant_with_the_tree_in_global_memory(pa, orc, monkeypatch):
+    # the same exchange when the scene does not fit LDS (long launches of large scenes run it by default; the
+    # 1024-lane kernel is forced here because the test's launch is short)
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(20000)
+    osc = oracle_scene(orc, sc)
+    W, H = 320, 180
+    crop = (96, 224, 60, 120)
+    x0, x1, y0, y1 = crop
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:2], crop=crop, threads=16)
+    monkeypatch.setenv("MI355PT_BLOCK", "1024")
+    for thr in (None, "12,8,24,65,65,32"):
+        if thr:
+            monkeypatch.setenv("MI355PT_XCHG_SCHED", thr)
+        for flags in (pa.FLAG_COUNT, 0):
+            with pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=flags) as r:
+                r.render(seeds=SEEDS[:2])
+                s = r.stats()
+                assert s["scene_in_lds"] == 0 and s["exchange_on"] == 1
+                if flags:
+                    assert s["exchange"]["lanes_deposited"] == s["exchange"]["lanes_withdrawn"] > 0
+                assert bits_equal(ref[y0:y1, x0:x1], r.read_accum()[y0:y1, x0:x1])
+    monkeypatch.setenv("MI355PT_XCHG_GLOBAL", "0")
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        r.render(seeds=SEEDS[:2])
+        assert r.stats()["exchange_on"] == 0
+        assert bits_equal(ref[y0:y1, x0:x1], r.read_accum()[y0:y1, x0:x1])
 
 
 def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
