@@ -1476,7 +1476,10 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     P.watchdog_ticks = sw.watchdog_ms * 100000ull;  // 100 MHz
     P.inv_tiles_x = 1.0f / (float)tiles_x;
     for (int k = 0; k < 6; k++) P.thr[k] = sw.thr[k];
-    P.chunk_max = sw.chunk ? sw.chunk : (d->scene_in_lds ? 32u : 4u);
+    // Units a wave takes from the queue at once (consecutive units are consecutive frames of one tile: the same
+    // pixels, so the same part of a large tree -- 1 M spheres at 3840x2160, 32 frames: 26.8 ms at 4 units,
+    // 24.6 at 8, 24.0 at 16 and 32; 10 M spheres 30.9 / 27.3 / 27.1 at 4 / 16 / 32; 8-frame launches are best at 16).
+    P.chunk_max = sw.chunk ? sw.chunk : ((d->scene_in_lds || std::min(n_frames, batch) >= 16u) ? 32u : 16u);
     // Short launches (fewer than about 56 64-path units per resident wave: below 15 frames at 1920x1080) are a
     // few per cent faster with the smaller workgroups; longer ones with 1024 lanes at 8 waves per SIMD (measured
     // at 1920x1080: 8 frames 1.15 ms with 512 lanes against 1.23 with 1024; 16 frames 1.75 / 1.74; 24 frames
