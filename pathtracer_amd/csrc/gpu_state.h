@@ -46,6 +46,7 @@ struct Switches {
     bool lockstep = false;      // MI355PT_KERNEL=lockstep: the simple kernel
     uint64_t watchdog_ms = 20000;  // MI355PT_WATCHDOG_MS
     uint32_t thr[6] = {12, 8, 24, 16, 6, 32};  // MI355PT_SCHED: step thresholds node, leaf, -, opaque, glass, restart
+    bool ordered_global = true;                 // MI355PT_NODES=plain: trees in global memory are walked as Node64 records
     bool exchange_global = true;                // MI355PT_XCHG_GLOBAL=0: no exchange variant for trees in global memory
     bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
     uint32_t xthr[6] = {12, 8, 24, 24, 12, 28}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
@@ -63,6 +64,9 @@ struct Device {
 
     char* scene = nullptr;
     size_t scene_cap = 0;
+    char* onodes = nullptr;  // direction-ordered records of a tree that stays in global memory (adopt_layout)
+    size_t onodes_cap = 0;
+    bool onodes_valid = false;
     SceneLayout layout{};
     bool have_scene = false;
     bool scene_in_lds = false;

@@ -118,6 +118,36 @@ struct HybridMem {
     }
     __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
+// The same with the nodes as direction-ordered 80-byte records (node_to_ordered) in an array of their own
+// (`onodes`, built by pt_order_nodes_kernel; the blob keeps its Node64 section, which this view never reads).
+// Links to interior nodes are the byte offsets of their records; the first `lds_node_bytes` bytes of the array
+// (whole records) are also in LDS.  A visit costs 12 vector instructions less than over Node64 (no min / max per
+// axis), which is what bounds the walk of a large tree once its fetches hit the L1 (see enqueue_in).
+constexpr uint32_t GLOBAL_NODE_BYTES = 80;
+struct HybridOrderedMem : HybridMem {
+    static constexpr bool ORDERED_NODES = true;
+    const char* onodes;
+    __device__ __forceinline__ void node_ordered(uint32_t a, const uint32_t* sgn, f4& ax, f4& ay, f4& az, u2& ch) const {
+        typedef uint32_t w2 __attribute__((ext_vector_type(2)));
+        typedef float v4 __attribute__((ext_vector_type(4), aligned(8)));
+        if (a < lds_node_bytes) {
+            const uint32_t l = lds_base + a;
+            auto four = [](uint32_t addr) {
+                const w2 lo = *reinterpret_cast<const PT_LDS(w2)*>(addr), hi = *reinterpret_cast<const PT_LDS(w2)*>(addr + 8u);
+                return f4{__uint_as_float(lo.x), __uint_as_float(lo.y), __uint_as_float(hi.x), __uint_as_float(hi.y)};
+            };
+            ax = four(l + sgn[0]), ay = four(l + 24u + sgn[1]), az = four(l + 48u + sgn[2]);
+            const w2 c = *reinterpret_cast<const PT_LDS(w2)*>(l + 72u);
+            ch = u2{c.x, c.y};
+        } else {
+            const char* p = onodes + a;
+            const v4 x = *reinterpret_cast<const v4*>(p + sgn[0]), y = *reinterpret_cast<const v4*>(p + 24u + sgn[1]),
+                     z = *reinterpret_cast<const v4*>(p + 48u + sgn[2]);
+            ax = f4{x.x, x.y, x.z, x.w}, ay = f4{y.x, y.y, y.z, y.w}, az = f4{z.x, z.y, z.z, z.w};
+            ch = *reinterpret_cast<const u2*>(p + 72u);
+        }
+    }
+};
 // Per-lane traversal stack in LDS, entry-major so that lane l always hits bank l % 64.
 template <int BLK>
 struct LdsStack {
@@ -186,6 +216,7 @@ struct RenderParams {
     uint32_t stack_lds_entries, stack_spill_entries;
     // Exchange variant of pt_render_sched_kernel: LDS offset of the workgroup's two path pools (0: not in use)
     uint32_t pool_off;
+    const char* onodes;  // SCENE_GLOBAL_ORDERED: the tree as direction-ordered records
 };
 
 // Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
@@ -201,6 +232,20 @@ constexpr uint32_t POOL_CAP = 64, POOL_HEADER = 64, POOL_BYTES = POOL_HEADER + 2
 constexpr uint32_t POOL_TUNING[4] = {PT_POOL_TUNING};
 constexpr uint32_t POOL_MIN_OPAQUE = POOL_TUNING[0], POOL_MIN_GLASS = POOL_TUNING[1];
 constexpr uint32_t POOL_DEP_MIN_OPAQUE = POOL_TUNING[2], POOL_DEP_MIN_GLASS = POOL_TUNING[3];
+
+// The direction-ordered records of a tree that stays in global memory (adopt_layout).
+__global__ void pt_order_nodes_kernel(const uint32_t* nodes64, uint32_t n, uint32_t* out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[16], rec[20];
+#pragma unroll
+    for (int k = 0; k < 16; k++) q[k] = nodes64[(size_t)i * 16u + k];
+    const uint32_t l0 = (int32_t)q[12] >= 0 ? q[12] * GLOBAL_NODE_BYTES : q[12];
+    const uint32_t l1 = (int32_t)q[13] >= 0 ? q[13] * GLOBAL_NODE_BYTES : q[13];
+    node_to_ordered(q, l0, l1, rec);
+#pragma unroll
+    for (int k = 0; k < 20; k++) out[(size_t)i * 20u + k] = rec[k];
+}
 
 __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -218,8 +263,10 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 
 // SCENE: where the scene blob is read from and which node format it holds.
 // SCENE_REFERENCE: memory as SCENE_GLOBAL, nodes walked the reference's way (SceneLayout::reference_walk).
-enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2, SCENE_REFERENCE = 3 };
+// SCENE_GLOBAL_ORDERED: memory as SCENE_GLOBAL, nodes read as direction-ordered records from RenderParams::onodes.
+enum { SCENE_GLOBAL = 0, SCENE_LDS = 1, SCENE_LDS_HALF = 2, SCENE_REFERENCE = 3, SCENE_GLOBAL_ORDERED = 4 };
 template <int SCENE> struct SceneMem { typedef HybridMem type; };
+template <> struct SceneMem<SCENE_GLOBAL_ORDERED> { typedef HybridOrderedMem type; };
 template <> struct SceneMem<SCENE_LDS> { typedef LdsOrderedMem type; };
 template <> struct SceneMem<SCENE_LDS_HALF> { typedef LdsMem type; };
 
@@ -229,7 +276,7 @@ template <int SCENE, int BLK>
 __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0) {
     typedef uint32_t w4 __attribute__((ext_vector_type(4)));
     typedef uint32_t w2 __attribute__((ext_vector_type(2)));
-    const w4* src = reinterpret_cast<const w4*>(P.scene);
+    const w4* src = reinterpret_cast<const w4*>(SCENE == SCENE_GLOBAL_ORDERED ? P.onodes : P.scene);
     if constexpr (SCENE == SCENE_LDS) {
         const uint32_t n = P.L.n_nodes;  // the node section starts the blob
         for (uint32_t i = threadIdx.x; i < n; i += BLK) {
@@ -291,6 +338,7 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
         mem.base = lds0;
     } else {
         mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
+        if constexpr (SCENE == SCENE_GLOBAL_ORDERED) mem.onodes = P.onodes;
         stack.spill = P.stack_spill + (size_t)blockIdx.x * P.stack_spill_entries * BLK + threadIdx.x;
         stack.lds_entries = (int32_t)P.stack_lds_entries;
     }
@@ -482,6 +530,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         mem.base = lds0;
     } else {
         mem.base = P.scene, mem.lds_base = lds0, mem.lds_node_bytes = P.scene_lds_bytes;
+        if constexpr (SCENE == SCENE_GLOBAL_ORDERED) mem.onodes = P.onodes;
         stack.spill = P.stack_spill + (size_t)blockIdx.x * P.stack_spill_entries * BLK + threadIdx.x;
         stack.lds_entries = (int32_t)P.stack_lds_entries;
     }
@@ -1029,6 +1078,10 @@ static void read_switches(Switches& s) {
     s.watchdog_ms = (uint64_t)std::max(1l, env_long("MI355PT_WATCHDOG_MS", 20000));
     s.exchange = env_long("MI355PT_XCHG", 1) != 0;
     s.exchange_global = env_long("MI355PT_XCHG_GLOBAL", 1) != 0;
+    {
+        const char* nodes = getenv("MI355PT_NODES");
+        s.ordered_global = !(nodes && strcmp(nodes, "plain") == 0);
+    }
     if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -1129,6 +1182,7 @@ void destroy(Device* d) {
     for (auto& t : d->timed) d->event_pool.push_back(t.begin), d->event_pool.push_back(t.end);
     for (hipEvent_t e : d->event_pool) (void)hipEventDestroy(e);
     (void)hipFree(d->scene);
+    (void)hipFree(d->onodes);
     (void)hipFree(d->accum);
     (void)hipFree(d->pixel_hash);
     (void)hipFree(d->frame_buf);
@@ -1194,6 +1248,27 @@ bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
         err = "scene: half-precision nodes are only walked from LDS";
         d->have_scene = false;
         return false;
+    }
+    // A tree that stays in global memory is walked through direction-ordered records, built here from the blob's
+    // Node64 section (MI355PT_NODES=plain keeps the Node64 walk); links are byte offsets, hence the size limit.
+    d->onodes_valid = false;
+    if (!d->scene_in_lds && !layout.reference_walk && layout.off_nodes == 0 && d->sw.ordered_global &&
+        (uint64_t)layout.n_nodes * GLOBAL_NODE_BYTES < (1ull << 31)) {
+        DeviceGuard guard(d->id);
+        const size_t need = (size_t)layout.n_nodes * GLOBAL_NODE_BYTES;
+        if (need > d->onodes_cap) {
+            (void)hipFree(d->onodes);
+            d->onodes = nullptr;
+            d->onodes_cap = 0;
+            PT_HIP(hipMalloc(&d->onodes, need));
+            d->onodes_cap = need;
+        }
+        hipLaunchKernelGGL(pt_order_nodes_kernel, dim3((layout.n_nodes + 255u) / 256u), dim3(256), 0, d->stream,
+                           reinterpret_cast<const uint32_t*>(d->scene + layout.off_nodes), layout.n_nodes,
+                           reinterpret_cast<uint32_t*>(d->onodes));
+        PT_HIP(hipGetLastError());
+        PT_HIP(hipStreamSynchronize(d->stream));
+        d->onodes_valid = true;
     }
     return true;
 }
@@ -1274,7 +1349,7 @@ static bool launch_render(Device* d, const RenderParams& P, uint32_t lds_bytes, 
     if constexpr (!COUNT) {
         if (fast) kern = pt_render_sched_kernel<SCENE, false, BLK, false, true>;
     }
-    if constexpr ((SCENE == SCENE_LDS || SCENE == SCENE_GLOBAL) && BLK == 1024) {  // exchange variant
+    if constexpr ((SCENE == SCENE_LDS || SCENE == SCENE_GLOBAL || SCENE == SCENE_GLOBAL_ORDERED) && BLK == 1024) {  // exchange variant
         if (P.pool_off && !lockstep) kern = pt_render_sched_kernel<SCENE, COUNT, BLK, true>;
         if constexpr (!COUNT) {
             if (P.pool_off && fast) kern = pt_render_sched_kernel<SCENE, false, BLK, true, true>;
@@ -1310,6 +1385,11 @@ static bool launch_render_blk(Device* d, const RenderParams& P, uint32_t lds_byt
     if (scene_mode == SCENE_REFERENCE)
         return count ? launch_render<SCENE_REFERENCE, true, BLK>(d, P, lds_bytes, lockstep, err)
                      : launch_render<SCENE_REFERENCE, false, BLK>(d, P, lds_bytes, lockstep, err);
+    if constexpr (BLK != 256) {  // the 256-lane instances (MI355PT_BLOCK=256 only) are not built for it
+        if (scene_mode == SCENE_GLOBAL_ORDERED)
+            return count ? launch_render<SCENE_GLOBAL_ORDERED, true, BLK>(d, P, lds_bytes, lockstep, err)
+                         : launch_render<SCENE_GLOBAL_ORDERED, false, BLK>(d, P, lds_bytes, lockstep, err);
+    }
     return count ? launch_render<SCENE_GLOBAL, true, BLK>(d, P, lds_bytes, lockstep, err)
                  : launch_render<SCENE_GLOBAL, false, BLK>(d, P, lds_bytes, lockstep, err);
 }
@@ -1486,8 +1566,8 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     // 2.39 / 2.26; 32 frames 3.03 / 2.78; 256 frames 7 % apart).
     const bool long_launch = (uint64_t)std::min(n_frames, batch) * tiles >= 56ull * 32ull * (uint64_t)d->prop.multiProcessorCount;
     const bool in_lds = d->scene_in_lds;
-    const int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
-                           : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
+    int scene_mode = d->layout.reference_walk ? SCENE_REFERENCE
+                     : in_lds ? (d->layout.node_half ? SCENE_LDS_HALF : SCENE_LDS) : SCENE_GLOBAL;
     const size_t lds_cu = 160u * 1024u;
     uint32_t block, lds_bytes;
     size_t spill_in_use = 0;  // entries of the spill area this call's kernels address
@@ -1538,15 +1618,19 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         const long budget = (long)(lds_cu / blocks_per_cu) - (long)stack_lds - 2048;  // LDS is granted in granules
         long cache = sw.node_cache_kb >= 0 ? sw.node_cache_kb * 1024 : budget;
         cache = std::min<long>(cache, (long)lds_cu - (long)stack_lds);
-        cache = std::min<long>(cache, 4096l * (long)sizeof(Node64));  // the renumbered prefix (order_top_first)
-        cache = std::min<long>(cache, (long)d->layout.n_nodes * (long)sizeof(Node64));
-        cache = std::max<long>(cache, 0) / 64 * 64;
+        if (scene_mode == SCENE_GLOBAL && d->onodes_valid && block != 256u) scene_mode = SCENE_GLOBAL_ORDERED, P.onodes = d->onodes;
+        const long node_bytes = scene_mode == SCENE_GLOBAL_ORDERED ? (long)GLOBAL_NODE_BYTES : (long)sizeof(Node64);
+        cache = std::min<long>(cache, 4096l * node_bytes);  // the renumbered prefix (order_top_first)
+        cache = std::min<long>(cache, (long)d->layout.n_nodes * node_bytes);
+        cache = std::max<long>(cache, 0) / node_bytes * node_bytes;  // whole records
         P.scene_lds_bytes = (d->layout.off_nodes == 0) ? (uint32_t)cache : 0u;
         lds_bytes = P.scene_lds_bytes + stack_lds;
         // Exchange variant, as for scenes in LDS (1 M spheres at 3840x2160, 32 frames: 28.5 -> 27.0 ms; 100 k spheres
         // 24.9 -> 23.6); the pools come out of the node prefix.
-        if (sw.exchange_global && sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 && scene_mode == SCENE_GLOBAL) {
-            if (P.scene_lds_bytes >= POOL_BYTES + 64u) P.scene_lds_bytes -= (POOL_BYTES + 63u) / 64u * 64u;
+        if (sw.exchange_global && sw.exchange && !lockstep && block == 1024u && cfg.samples == 1 &&
+            (scene_mode == SCENE_GLOBAL || scene_mode == SCENE_GLOBAL_ORDERED)) {
+            if (P.scene_lds_bytes >= POOL_BYTES + 2u * (uint32_t)node_bytes)
+                P.scene_lds_bytes -= (POOL_BYTES + (uint32_t)node_bytes - 1u) / (uint32_t)node_bytes * (uint32_t)node_bytes;
             lds_bytes = P.scene_lds_bytes + stack_lds;
             P.pool_off = (lds_bytes + 15u) & ~15u;
             lds_bytes = P.pool_off + POOL_BYTES;

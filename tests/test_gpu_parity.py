@@ -268,6 +268,34 @@ def test_exchange_variant_with_the_tree_in_global_memory(pa, orc, monkeypatch):
         assert bits_equal(ref[y0:y1, x0:x1], r.read_accum()[y0:y1, x0:x1])
 
 
+def test_trees_in_global_memory_walked_as_ordered_or_plain_records(pa, orc, monkeypatch):
+    # A tree that stays in global memory is walked through direction-ordered 80-byte records built on the device
+    # (MI355PT_NODES=plain: through the blob's own 64-byte nodes).  The same boxes either way: the same image, the
+    # same node visits and sphere tests, with every workgroup size and with the tree built on the device.
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(20000)
+    osc = oracle_scene(orc, sc)
+    W, H = 320, 180
+    crop = (96, 224, 60, 120)
+    x0, x1, y0, y1 = crop
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:2], crop=crop, threads=16)
+    counts = {}
+    for nodes in ("ordered", "plain"):
+        if nodes == "plain":
+            monkeypatch.setenv("MI355PT_NODES", "plain")
+        for block in ("512", "1024"):
+            monkeypatch.setenv("MI355PT_BLOCK", block)
+            for mode in (pa.BVH_SAH, pa.BVH_LBVH):
+                with pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=pa.FLAG_COUNT, bvh_mode=mode) as r:
+                    r.render(seeds=SEEDS[:2])
+                    s = r.stats()
+                    assert s["scene_in_lds"] == 0
+                    assert bits_equal(ref[y0:y1, x0:x1], r.read_accum()[y0:y1, x0:x1])
+                    counts.setdefault((block, mode), []).append((s["nodes"], s["tests"], s["rays"]))
+    for k, v in counts.items():
+        assert v[0] == v[1], k
+
+
 def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
     # render_async queues launches without joining; frames must still be added in order, also when a
     # call is split into several launches (forced here: 64 frames per launch)
