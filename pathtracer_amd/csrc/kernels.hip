@@ -140,11 +140,12 @@ struct HybridOrderedMem : HybridMem {
             const w2 c = *reinterpret_cast<const PT_LDS(w2)*>(l + 72u);
             ch = u2{c.x, c.y};
         } else {
-            const char* p = onodes + a;
-            const v4 x = *reinterpret_cast<const v4*>(p + sgn[0]), y = *reinterpret_cast<const v4*>(p + 24u + sgn[1]),
-                     z = *reinterpret_cast<const v4*>(p + 48u + sgn[2]);
+            // 32-bit offsets from the uniform base: one address register per fetch
+            const uint32_t o0 = a + sgn[0], o1 = a + sgn[1], o2 = a + sgn[2];
+            const v4 x = *reinterpret_cast<const v4*>(onodes + o0), y = *reinterpret_cast<const v4*>(onodes + o1 + 24u),
+                     z = *reinterpret_cast<const v4*>(onodes + o2 + 48u);
             ax = f4{x.x, x.y, x.z, x.w}, ay = f4{y.x, y.y, y.z, y.w}, az = f4{z.x, z.y, z.z, z.w};
-            ch = *reinterpret_cast<const u2*>(p + 72u);
+            ch = *reinterpret_cast<const u2*>(onodes + a + 72u);
         }
     }
 };
