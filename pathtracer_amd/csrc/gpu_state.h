@@ -37,7 +37,7 @@ struct Switches {
     uint32_t max_batch = 0;     // MI355PT_MAX_BATCH: frames per launch (0: what the frame buffer holds)
     uint32_t frame_buf_gb = 0;  // MI355PT_FRAME_BUF_GB: frame buffer budget (0: FRAME_BUF_DEFAULT_BYTES)
     uint32_t block = 0;         // MI355PT_BLOCK: workgroup size 256 | 512 | 1024 (0: chosen per launch)
-    long stack_lds = 6;         // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
+    long stack_lds = 5;         // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
     long node_cache_kb = -1;    // MI355PT_NODE_CACHE_KB: node prefix kept in LDS for those scenes (-1: what fits)
     bool tile_order = true;     // MI355PT_TILE_ORDER=0: tiles in row-major order
     uint32_t chunk = 0;         // MI355PT_CHUNK: largest work-queue chunk in units (0: 32 for LDS scenes, else 4)

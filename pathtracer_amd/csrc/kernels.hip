@@ -1107,7 +1107,7 @@ static void read_switches(Switches& s) {
     s.max_batch = (uint32_t)std::max(0l, env_long("MI355PT_MAX_BATCH", 0));
     s.frame_buf_gb = (uint32_t)std::max(0l, env_long("MI355PT_FRAME_BUF_GB", 0));
     s.block = (uint32_t)env_long("MI355PT_BLOCK", 0);
-    s.stack_lds = env_long("MI355PT_STACK_LDS", 6);
+    s.stack_lds = env_long("MI355PT_STACK_LDS", 5);
     s.node_cache_kb = env_long("MI355PT_NODE_CACHE_KB", -1);
     s.tile_order = env_long("MI355PT_TILE_ORDER", 1) != 0;
     s.chunk = (uint32_t)std::min(1024l, std::max(0l, env_long("MI355PT_CHUNK", 0)));
@@ -1645,7 +1645,8 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         // as much of the top of the tree as still lets 24 waves stay resident on a CU.  Measured on
         // MI355X with 1 M spheres at 3840x2160: 6 entries + 40 KB of nodes in 512-lane workgroups
         // 18.3 ms per 16 frames; everything in global memory 21.7 ms; a 64 KB prefix at 8 waves per CU
-        // 33 ms (occupancy matters more than the size of the prefix).
+        // 33 ms (occupancy matters more than the size of the prefix).  With today's kernel 5 entries are slightly
+        // better than 6 (1 M spheres, 64 frames: 43.0 against 43.3 ms; 10 M spheres, 32 frames: 25.3 against 25.9).
         // MI355PT_STACK_LDS (entries) and MI355PT_NODE_CACHE_KB override the split (development).
         block = (lockstep || !long_launch) ? 512u : 1024u;  // the scheduled kernel's 1024-lane instance runs 8 waves per SIMD
         if (sw.block == 256 || sw.block == 512 || sw.block == 1024) block = sw.block;
