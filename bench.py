@@ -77,6 +77,12 @@ def main():
     ap.add_argument("--no-rmse", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: what libraries print there while they start up (RCCL's
+    # version banner, gloo's connection lines) goes to stderr; the descriptor comes back for the final print
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -259,7 +265,10 @@ def main():
                           f"restatement of the reference algorithm (reference BVH topology, 48-B nodes), "
                           f"{cdt:.1f} s wall",
             }
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     r.close()
     if use_dist:
         dist.barrier()   # rank 0's reporting legs are over: all ranks leave the group together
