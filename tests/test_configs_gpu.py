@@ -146,6 +146,36 @@ def test_reduce_over_contexts(pa):
             r.close()
 
 
+def test_c5_ten_million_spheres_partitioned_over_eight_contexts(pa):
+    # C5 in miniature: the 10 M-sphere scene at 4K, its frames split eight ways by mi355pt_partition_frames
+    # (the eight contexts share this box's one device; on an eight-GPU node each would have its own and the sum
+    # would go through RCCL), one mi355pt_reduce to the root.  Against one context that renders every frame only
+    # the order of the float additions differs (bound of the multi-GPU path: 1e-6 relative).  Trees built on the
+    # device: eight host builds of this scene would take a quarter of a minute.
+    from pathtracer_amd import synth
+    sc = synth.plane_scene(10_000_000)
+    W, H, F, N = 3840, 2160, 16, 8
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) as r:
+        r.render(F)
+        one, st_one = r.read_accum(), r.stats()
+    assert st_one["scene_in_lds"] == 0 and st_one["paths"] == W * H * F
+    rs = [pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) for _ in range(N)]
+    try:
+        for k, r in enumerate(rs):
+            first, count = pa.partition_frames(F, N, k)
+            assert count == F // N
+            r.render(seeds=seeds_of(pa, count, first), wait=False)
+        pa.reduce(rs, root=0)
+        acc, st = rs[0].read_accum(), rs[0].stats()
+        assert rs[0].samples() == F and st["paths"] == st_one["paths"] and st["rays"] == st_one["rays"]
+        assert np.all(acc[..., 3] == 1.0) and np.isfinite(acc).all()
+        rel = np.abs(acc[..., :3] - one[..., :3]) / np.maximum(1.0, np.abs(one[..., :3]))
+        assert rel.max() <= 2e-6 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 1e-6
+    finally:
+        for r in rs:
+            r.close()
+
+
 def test_reduce_comm_with_a_one_rank_rccl_communicator(pa):
     # mi355pt_reduce_comm with a communicator the caller made (here: RCCL's ncclCommInitAll over this box's one
     # device, through ctypes): the ncclReduce the library issues on the context's stream, on a group of one, must
