@@ -1299,7 +1299,11 @@ bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
             (void)hipFree(d->onodes);
             d->onodes = nullptr;
             d->onodes_cap = 0;
-            PT_HIP(hipMalloc(&d->onodes, need));
+            if (hipMalloc(&d->onodes, need) != hipSuccess) {  // no room for the second copy: the Node64 walk needs none
+                (void)hipGetLastError();
+                d->onodes = nullptr;
+                return true;
+            }
             d->onodes_cap = need;
         }
         hipLaunchKernelGGL(pt_order_nodes_kernel, dim3((layout.n_nodes + 255u) / 256u), dim3(256), 0, d->stream,
