@@ -4,6 +4,7 @@
 // tests/conftest.py into tests/emul/ and is not part of libmi355pt.so.
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -70,8 +71,26 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
         }
         omem.nodes = ordered_nodes.data();
     }
+    // A float-node tree that stays in global memory is walked through the same records, 80 bytes apart, links as
+    // byte offsets (the device builds them when it adopts the scene; MI355PT_NODES=plain walks the Node64 records).
+    const char* nodes_env = getenv("MI355PT_NODES");
+    const bool ordered_global = !ordered && !L.node_half && !L.reference_walk && !(nodes_env && strcmp(nodes_env, "plain") == 0) &&
+                                (uint64_t)L.n_nodes * 80u < (1ull << 31);
+    if (ordered_global) {
+        ordered_nodes.resize((size_t)L.n_nodes * 80u);
+        for (uint32_t i = 0; i < L.n_nodes; i++) {
+            uint32_t q[16], rec[20];
+            memcpy(q, blob.data() + L.off_nodes + (size_t)i * 64u, 64);
+            const uint32_t l0 = (int32_t)q[12] >= 0 ? q[12] * 80u : q[12];
+            const uint32_t l1 = (int32_t)q[13] >= 0 ? q[13] * 80u : q[13];
+            node_to_ordered(q, l0, l1, rec);
+            memcpy(ordered_nodes.data() + (size_t)i * 80u, rec, 80);
+        }
+        omem.nodes = ordered_nodes.data();
+    }
     if (bvh_info && ordered) bvh_info[3] = 2;
     if (bvh_info && L.reference_walk) bvh_info[3] = 3;
+    if (bvh_info && ordered_global) bvh_info[3] = 4;
     Camera64 cam64v;
     memcpy(&cam64v, cam64, 64);
     CameraRegs cam = load_camera(cam64v);
@@ -121,7 +140,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                             }
                             walk_result(w, hit);
                         } else if (L.reference_walk) closest_hit<PtrMem, HostStack, true, false, true>(mem, L, st, ps.o, ps.d, hit, cnt);
-                        else if (ordered) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
+                        else if (ordered || ordered_global) closest_hit<PtrOrderedMem, HostStack, true, false>(omem, L, st, ps.o, ps.d, hit, cnt);
                         else if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
                         else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;

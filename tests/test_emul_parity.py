@@ -123,7 +123,7 @@ def test_unknown_material_is_black_and_short_circuit_flag(emul, orc, pa):
     assert not bits_equal(always, ref1)
 
 
-def test_synthetic_plane_scene_crop(emul, orc, pa):
+def test_synthetic_plane_scene_crop(emul, orc, pa, monkeypatch):
     from pathtracer_amd import synth
     sc = synth.plane_scene(5000)
     osc = oracle_scene(orc, sc)
@@ -132,10 +132,15 @@ def test_synthetic_plane_scene_crop(emul, orc, pa):
     crop = (100, 164, 60, 96)
     ref, st = orc.render(osc, cam, W, H, SEEDS[:2], crop=crop, threads=4)
     acc, cnt, info = emul.render(sc, cam, W, H, SEEDS[:2], crop=crop)
-    assert info[3] == 0                       # too large for LDS: plain 64-byte nodes
+    assert info[3] == 4                       # too large for LDS: direction-ordered records in global memory
     assert bits_equal(ref, acc)
     # the SAH tree visits far fewer nodes than the reference's z-only split
     assert cnt["nodes"] * 2 < st["interior_visits"]
+    # the same tree through its plain 64-byte nodes: the same boxes, so the same image and the same visits
+    monkeypatch.setenv("MI355PT_NODES", "plain")
+    acc_p, cnt_p, info_p = emul.render(sc, cam, W, H, SEEDS[:2], crop=crop)
+    assert info_p[3] == 0 and bits_equal(ref, acc_p)
+    assert cnt_p["nodes"] == cnt["nodes"] and cnt_p["tests"] == cnt["tests"]
 
 
 def test_sah_tree_is_shallower_in_work_than_reference_tree(emul, orc, pa):
@@ -208,7 +213,7 @@ def test_half_precision_nodes_are_chosen_when_only_they_fit_lds(emul, orc, pa):
     far.spheres["pos"][4:, 0] += np.float32(30000.0)
     far.spheres["pos"][4:400, 0] -= np.float32(60000.0)
     _, _, info_far = emul.render(far, cam, 16, 9, SEEDS[:1])
-    assert info_far[3] == 0
+    assert info_far[3] == 4   # float boxes, too large for LDS: ordered records in global memory
 
 
 @pytest.mark.parametrize("k_top", [1, 64, 4096, 10 ** 9])
