@@ -9,6 +9,7 @@
 
 #include "gpu.h"
 #include "pt_types.h"
+#include "pt_device.h"
 
 namespace pt {
 namespace gpu {
@@ -50,6 +51,8 @@ struct Switches {
     bool exchange_global = true;                // MI355PT_XCHG_GLOBAL=0: no exchange variant for trees in global memory
     bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
     uint32_t xthr[6] = {12, 8, 24, 24, 12, 28}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
+    bool tile_lists = true;                     // MI355PT_TILE_LISTS=0: camera rays walk the tree like every other ray
+    uint32_t tile_list_max = TILE_LIST_CAP;     // MI355PT_TILE_LIST_MAX: tiles with more candidates keep the walk
 };
 // Results of one launch wait in a frame buffer for the accumulation kernel; it is at most this large (and at
 // most a quarter of the free device memory): 334 frames at 1920x1080, 84 at 3840x2160.
@@ -88,6 +91,11 @@ struct Device {
     uint32_t since_measure = 0;  // launches since the tile costs were last measured
     Camera64 perm_cam{};
     int32_t perm_depth = 0, perm_samples = 0;
+    // Candidate lists of the camera rays (pt_tile_lists_kernel): [tiles][TILE_LIST_WORDS], allocated with the
+    // accumulator, rebuilt on the render stream when camera, scene or image size changed
+    uint32_t* tile_lists = nullptr;
+    bool lists_valid = false;
+    Camera64 lists_cam{};
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
     size_t seeds_cap = 0, seeds_head = 0;
     std::deque<std::vector<uint32_t>> seed_staging;  // host copies kept alive until finish()

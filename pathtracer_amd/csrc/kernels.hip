@@ -218,6 +218,7 @@ struct RenderParams {
     // Exchange variant of pt_render_sched_kernel: LDS offset of the workgroup's two path pools (0: not in use)
     uint32_t pool_off;
     const char* onodes;  // SCENE_GLOBAL_ORDERED: the tree as direction-ordered records
+    const uint32_t* tile_lists;  // pt_render_sched_kernel: per tile TILE_LIST_WORDS words, the candidates of its camera rays (null: none)
 };
 
 // Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
@@ -259,6 +260,21 @@ __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= w * h) return;
     out[i] = pixel_hash(i % w, i / w, w, h);
+}
+
+// Candidate lists of the camera rays, one thread per 8x8 tile (tile_list_build): once per camera, scene and image
+// size.  Reads the blob in global memory whatever the path kernels stage in LDS.
+__global__ void pt_tile_lists_kernel(const char* scene, SceneLayout L, Camera64 cam, uint32_t width, uint32_t height,
+                                     uint32_t tiles_x, uint32_t tiles, uint32_t max_list, uint32_t* lists) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= tiles) return;
+    PtrMem mem{scene};
+    uint32_t rec[TILE_LIST_WORDS];
+    for (uint32_t k = 1; k < TILE_LIST_WORDS; k++) rec[k] = 0u;
+    tile_list_build(mem, L, cam, t % tiles_x, t / tiles_x, width, height, max_list, rec);
+    typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+    w4* out = reinterpret_cast<w4*>(lists + (size_t)t * TILE_LIST_WORDS);
+    for (uint32_t k = 0; k < TILE_LIST_WORDS / 4u; k++) out[k] = w4{rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]};
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -934,6 +950,19 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 ps.bounce = 0;
                 walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
                 if constexpr (FAST) lane_rays++; else rays++;
+                if constexpr (SCENE != SCENE_REFERENCE) {
+                    // Camera rays test the candidates of their tile instead of walking the tree (tile_list_build);
+                    // the lanes of a restart step share a tile or two, so the loop below runs nearly uniform.
+                    if (Q->tile_lists) {
+                        const uint32_t tile_id = (pxy_now >> 19) * Q->tiles_x + ((pxy_now & 0xffffu) >> 3);
+                        const uint32_t* rec = Q->tile_lists + (size_t)tile_id * TILE_LIST_WORDS;
+                        const uint32_t n = rec[0];
+                        if (n != TILE_LIST_WALK) {
+                            for (uint32_t k = 0; k < n; k++) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, rec[1u + k], cnt);
+                            w.cur = WALK_FINISHED;
+                        }
+                    }
+                }
             }
         }
         if (!ran) {
@@ -1121,6 +1150,8 @@ static void read_switches(Switches& s) {
         const char* nodes = getenv("MI355PT_NODES");
         s.ordered_global = !(nodes && strcmp(nodes, "plain") == 0);
     }
+    s.tile_lists = env_long("MI355PT_TILE_LISTS", 1) != 0;
+    s.tile_list_max = (uint32_t)std::min<long>(TILE_LIST_CAP, std::max(0l, env_long("MI355PT_TILE_LIST_MAX", TILE_LIST_CAP)));
     if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
         unsigned t[6];
         if (sscanf(senv, "%u,%u,%u,%u,%u,%u", &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]) == 6)
@@ -1228,6 +1259,7 @@ void destroy(Device* d) {
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
     (void)hipFree(d->rank_chunk);
+    (void)hipFree(d->tile_lists);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
@@ -1282,6 +1314,7 @@ bool adopt_layout(Device* d, const SceneLayout& layout, std::string& err) {
     d->layout = layout;
     d->have_scene = true;
     d->perm_valid = false;
+    d->lists_valid = false;
     d->scene_in_lds = !layout.reference_walk && lds_scene_bytes(layout) + stack_bytes(layout, 256) <= LDS_SCENE_LIMIT;
     if (layout.node_half && !d->scene_in_lds) {
         err = "scene: half-precision nodes are only walked from LDS";
@@ -1329,7 +1362,10 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     (void)hipFree(d->tile_cost);
     (void)hipFree(d->tile_perm);
     (void)hipFree(d->rank_chunk);
+    (void)hipFree(d->tile_lists);
     d->rank_chunk = nullptr;
+    d->tile_lists = nullptr;
+    d->lists_valid = false;
     d->accum = nullptr;
     d->pixel_hash = nullptr;
     d->tile_cost = nullptr, d->tile_perm = nullptr;
@@ -1340,6 +1376,7 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     PT_HIP(hipMalloc(&d->tile_cost, n_tiles * sizeof(float)));
     PT_HIP(hipMalloc(&d->tile_perm, n_tiles * sizeof(uint32_t)));
     PT_HIP(hipMalloc(&d->rank_chunk, n_tiles * sizeof(uint16_t)));
+    PT_HIP(hipMalloc(&d->tile_lists, n_tiles * TILE_LIST_WORDS * sizeof(uint32_t)));
     d->width = width, d->height = height, d->n_pix = n_pix;
     hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
                        height);
@@ -1725,6 +1762,19 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
 
     // From here on work is queued: whatever fails, finish() has to run before the buffers are touched again.
     d->in_flight = true;
+    // Candidate lists of the camera rays: rebuilt on the stream, ahead of the launches that read them, when the
+    // camera, the scene or the image size changed (no allocation: the buffer came with the accumulator).  The
+    // reference-walk mode tries exactly the spheres the reference's walk tries, so it keeps the walk.
+    if (sw.tile_lists && !lockstep && !d->layout.reference_walk && d->tile_lists) {
+        if (!d->lists_valid || memcmp(&cam, &d->lists_cam, sizeof cam) != 0) {
+            hipLaunchKernelGGL(pt_tile_lists_kernel, dim3((tiles + 63u) / 64u), dim3(64), 0, d->stream, d->scene, d->layout, cam,
+                               d->width, d->height, tiles_x, tiles, sw.tile_list_max, d->tile_lists);
+            PT_HIP(hipGetLastError());
+            d->lists_valid = true;
+            d->lists_cam = cam;
+        }
+        P.tile_lists = d->tile_lists;
+    }
     uint32_t* dev_seeds;
     if (fixed) {
         // the caller's array is read before this call returns (render_static waits), so it needs no host copy

@@ -709,4 +709,153 @@ PT_FN void tile_pixel(uint32_t unit, uint32_t slot, uint32_t tiles_x, uint32_t& 
     py = ty * 8u + (slot >> 3);
 }
 
+// ---- camera rays: per-tile candidate lists ------------------------------------------------------
+// Every camera ray of an 8x8 tile starts at the camera position and points into the cone spanned by
+// the tile's four corner directions, whatever the frame and its jitter (compute.wgsl:405-413: the
+// jittered pixel position stays inside the pixel).  Which spheres such a ray can reach is therefore a
+// property of camera, tile and scene, not of the frame: the cull that a wave-uniform walk of the tree
+// would repeat identically in every frame is done once per camera instead, and its outcome -- the few
+// spheres whose padded ball meets the cone -- is kept as a short list per tile.  A camera ray then tests
+// exactly those spheres (the same sphere arithmetic, so the same closest hit: ties resolve by rank
+// whatever the order) and walks no tree.  Like the box tests of the walk, the cull never reaches a pixel
+// value; it keeps the reference's 0.01 padding (bounding_box.rs:17-27) plus a slack for the rounding of
+// the direction arithmetic.  Tiles whose list would be long (the horizon of a large plane) keep the walk.
+constexpr uint32_t TILE_LIST_WORDS = 16;                    // per tile: count, then up to 15 leaf-order sphere indices
+constexpr uint32_t TILE_LIST_CAP = TILE_LIST_WORDS - 1u;
+constexpr uint32_t TILE_LIST_WALK = 0xffffffffu;            // count word: camera rays of this tile walk the tree
+struct TileCone {
+    double n[4][3];   // unit normals of the four side planes through the camera position, pointing inwards
+    double org[3];    // camera position
+    double ang_err;   // bound on the angle between a computed (binary32) direction and the exact one
+    bool valid;
+};
+PT_FN void tile_cone(const Camera64& cam, uint32_t tx, uint32_t ty, uint32_t w, uint32_t h, TileCone& c) {
+    const double margin = 0.01;  // pixels; covers the rounding of (px + r) / w and of 2u - 1 (< 1e-3 pixel at 65535)
+    const double x0 = 8.0 * tx - margin, x1 = 8.0 * tx + 8.0 + margin, y0 = 8.0 * ty - margin, y1 = 8.0 * ty + 8.0 + margin;
+    const double nx[2] = {2.0 * x0 / w - 1.0, 2.0 * x1 / w - 1.0}, ny[2] = {-(2.0 * y0 / h - 1.0), -(2.0 * y1 / h - 1.0)};
+    double d[4][3], dc[3], mag = 0.0;
+    for (int a = 0; a < 3; a++) {
+        const double base = (double)cam.center[a] - (double)cam.pos[a], hx = cam.horizontal[a], vy = cam.vertical[a];
+        d[0][a] = base + hx * nx[0] + vy * ny[0];  // corners in order around the tile
+        d[1][a] = base + hx * nx[1] + vy * ny[0];
+        d[2][a] = base + hx * nx[1] + vy * ny[1];
+        d[3][a] = base + hx * nx[0] + vy * ny[1];
+        dc[a] = base + hx * 0.5 * (nx[0] + nx[1]) + vy * 0.5 * (ny[0] + ny[1]);
+        c.org[a] = cam.pos[a];
+        mag += fabs((double)cam.center[a]) + fabs((double)cam.pos[a]) + fabs(hx) + fabs(vy);
+    }
+    bool ok = true;
+    double min_len = INFINITY;
+    for (int k = 0; k < 4; k++) {
+        const double* A = d[k];
+        const double* B = d[(k + 1) & 3];
+        double n[3] = {A[1] * B[2] - A[2] * B[1], A[2] * B[0] - A[0] * B[2], A[0] * B[1] - A[1] * B[0]};
+        const double len = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double la = sqrt(A[0] * A[0] + A[1] * A[1] + A[2] * A[2]);
+        min_len = fmin(min_len, la);
+        if (!(len > 1e-300) || !(la > 1e-30) || !(len < INFINITY)) {
+            ok = false;
+            break;
+        }
+        const double s = (n[0] * dc[0] + n[1] * dc[1] + n[2] * dc[2]) < 0.0 ? -1.0 / len : 1.0 / len;
+        for (int a = 0; a < 3; a++) c.n[k][a] = n[a] * s;
+        // the other two corners and the centre lie strictly inside: the four half-spaces bound a convex cone
+        const double* C = d[(k + 2) & 3];
+        const double* D = d[(k + 3) & 3];
+        const double ic = c.n[k][0] * C[0] + c.n[k][1] * C[1] + c.n[k][2] * C[2];
+        const double id = c.n[k][0] * D[0] + c.n[k][1] * D[1] + c.n[k][2] * D[2];
+        const double icen = c.n[k][0] * dc[0] + c.n[k][1] * dc[1] + c.n[k][2] * dc[2];
+        if (!(ic > 0.0) || !(id > 0.0) || !(icen > 0.0)) ok = false;
+        if (!((A[0] * dc[0] + A[1] * dc[1] + A[2] * dc[2]) > 0.0)) ok = false;  // narrower than a half-space
+    }
+    // center + horizontal * nx + vertical * ny - pos in binary32: four roundings of terms of size `mag`
+    c.ang_err = ok ? 4.0 * 1.2e-7 * mag / min_len + 1e-6 : 0.0;
+    c.valid = ok && c.ang_err < 1e-3;
+}
+// May a camera ray of the tile reach the ball of radius `rad` around (cx, cy, cz)?  (Never false for one that can.)
+PT_FN bool tile_cone_meets_ball(const TileCone& c, double cx, double cy, double cz, double rad) {
+    const double ox = cx - c.org[0], oy = cy - c.org[1], oz = cz - c.org[2];
+    const double dist = sqrt(ox * ox + oy * oy + oz * oz);
+    const double reach = rad * (1.0 + 1e-5) + 0.01 + c.ang_err * (dist + rad);
+    for (int k = 0; k < 4; k++)
+        if (c.n[k][0] * ox + c.n[k][1] * oy + c.n[k][2] * oz < -reach) return false;
+    return true;
+}
+// The same for an axis-aligned box (a node's child box, which already holds its spheres' padding).
+PT_FN bool tile_cone_meets_box(const TileCone& c, const float lo[3], const float hi[3]) {
+    double far2 = 0.0, l[3], u[3];
+    for (int a = 0; a < 3; a++) {
+        l[a] = (double)lo[a] - c.org[a], u[a] = (double)hi[a] - c.org[a];
+        const double m = fmax(fabs(l[a]), fabs(u[a]));
+        far2 += m * m;
+    }
+    const double slack = c.ang_err * sqrt(far2) + 1e-9;
+    for (int k = 0; k < 4; k++) {
+        double best = 0.0;  // the corner furthest along the inward normal
+        for (int a = 0; a < 3; a++) best += fmax(c.n[k][a] * l[a], c.n[k][a] * u[a]);
+        if (best < -slack) return false;
+    }
+    return true;
+}
+// Candidate list of tile (tx, ty) into rec[TILE_LIST_WORDS]: rec[0] = count <= max_list and the leaf-order
+// indices behind it, or rec[0] = TILE_LIST_WALK.  Walks the Node64 tree when the blob holds one, else (binary16
+// nodes: scenes of at most a few thousand spheres) looks at every sphere.
+template <class Mem>
+PT_FN void tile_list_build(const Mem& mem, const SceneLayout& L, const Camera64& cam, uint32_t tx, uint32_t ty, uint32_t w,
+                           uint32_t h, uint32_t max_list, uint32_t* rec) {
+    TileCone cone;
+    tile_cone(cam, tx, ty, w, h, cone);
+    if (!cone.valid) {
+        rec[0] = TILE_LIST_WALK;
+        return;
+    }
+    uint32_t count = 0;
+    bool overflow = false;
+    auto offer = [&](uint32_t si) {
+        const f4 s = mem.template load<f4>(L.off_spheres + si * 16u);  // x, y, z, rad * rad
+        if (!tile_cone_meets_ball(cone, s.x, s.y, s.z, sqrt((double)s.w))) return;
+        if (count >= max_list) {
+            overflow = true;
+            return;
+        }
+        rec[1u + count++] = si;
+    };
+    if (L.node_half) {
+        for (uint32_t si = 0; si < L.n_spheres && !overflow; si++) offer(si);
+    } else {
+        constexpr int STACK = 64;
+        int32_t stack[STACK];
+        int sp = 0;
+        stack[sp++] = 0;
+        while (sp > 0 && !overflow) {
+            const int32_t link = stack[--sp];
+            if (link < 0) {
+                const uint32_t ref = ~(uint32_t)link, first = ref & LEAF_FIRST_MASK, n = (ref >> LEAF_COUNT_SHIFT) + 1u;
+                for (uint32_t k = 0; k < n; k++) offer(first + k);
+                continue;
+            }
+            f4 q0, q1, q2;
+            u2 ch;
+            mem.node64(L.off_nodes + (uint32_t)link * 64u, q0, q1, q2, ch);
+            const float lo0[3] = {q0.x, q0.y, q0.z}, hi0[3] = {q0.w, q1.x, q1.y};
+            const float lo1[3] = {q1.z, q1.w, q2.x}, hi1[3] = {q2.y, q2.z, q2.w};
+            const bool in0 = tile_cone_meets_box(cone, lo0, hi0), in1 = tile_cone_meets_box(cone, lo1, hi1);
+            if (sp + 2 > STACK) {  // deeper than any tree the builders make: keep the walk
+                overflow = true;
+                break;
+            }
+            if (in0) stack[sp++] = (int32_t)ch.x;
+            if (in1) stack[sp++] = (int32_t)ch.y;
+        }
+    }
+    rec[0] = overflow ? TILE_LIST_WALK : count;
+}
+// Closest hit of a camera ray over its tile's candidate list: what the walk finds, without the walk.
+template <class Mem, bool COUNT>
+PT_FN void walk_tile_list(const Mem& mem, const SceneLayout& L, Walk& w, V3 o, V3 d, const uint32_t* rec, Counters& cnt) {
+    const uint32_t n = rec[0];
+    for (uint32_t k = 0; k < n; k++) walk_test_sphere<Mem, COUNT>(mem, L, w, o, d, rec[1u + k], cnt);
+    w.cur = WALK_FINISHED;
+}
+
 }  // namespace pt

@@ -65,6 +65,14 @@ def emul():
     L.emul_det_sin.restype = C.c_float
     L.emul_det_sin.argtypes = [C.c_float]
     L.emul_set_brute_force.argtypes = [C.c_int]
+    L.emul_set_tile_lists.argtypes = [C.c_int, C.c_uint32]
+
+    def tile_list_stats():
+        out = (C.c_uint64 * 4)()
+        L.emul_tile_list_stats(out)
+        return dict(zip(["list_rays", "list_tests", "walk_tiles", "list_tiles"], [int(v) for v in out]))
+
+    L.tile_list_stats = tile_list_stats
 
     def render(sc, cam, W, H, seeds, samples=1, depth=50, ref_topo=0, ref_nodes=None, crop=None, glass=1):
         acc = np.zeros((H, W, 4), np.float32)

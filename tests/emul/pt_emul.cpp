@@ -24,6 +24,9 @@ struct HostStack {
 };
 std::string g_err;
 int g_brute_force = 0;
+int g_tile_lists = 1;         // camera rays test their tile's candidate list (the device's default) instead of walking
+uint32_t g_tile_list_max = TILE_LIST_CAP;
+uint64_t g_list_rays = 0, g_list_tests = 0, g_walk_tiles = 0, g_list_tiles = 0;
 bool g_log = true;
 }  // namespace
 
@@ -33,6 +36,10 @@ const char* emul_error() { return g_err.c_str(); }
 // 1: closest hits are found by testing every sphere (no tree, no boxes); 2: the same with each sphere's own
 // padded box as the only cull, logging every root that box would hide
 void emul_set_brute_force(int mode) { g_brute_force = mode; }
+// on = 0: camera rays walk the tree like every other ray; max_list: longest list a tile may have before its rays walk
+void emul_set_tile_lists(int on, uint32_t max_list) { g_tile_lists = on, g_tile_list_max = max_list < TILE_LIST_CAP ? max_list : TILE_LIST_CAP; }
+// camera rays served by a list, sphere tests they made, tiles that keep the walk, tiles with a list (last render)
+void emul_tile_list_stats(uint64_t* out) { out[0] = g_list_rays, out[1] = g_list_tests, out[2] = g_walk_tiles, out[3] = g_list_tiles; }
 
 // counters: nodes, tests, accepted, bounce[5], rays, paths
 int emul_render(const void* spheres32, size_t n_spheres, const void* lights, size_t n_lights, const void* lamb,
@@ -97,9 +104,27 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     Counters cnt = {0, 0, 0};
     uint64_t big[10] = {0};
     const float fw = (float)w, fh = (float)h;
+    // per-tile candidate lists for camera rays, built on first use with the code the device's list kernel runs
+    const bool use_lists = g_tile_lists && !g_brute_force && !L.reference_walk;
+    const uint32_t tiles_x = (w + 7u) / 8u, tiles_y = (h + 7u) / 8u;
+    std::vector<uint32_t> lists;
+    std::vector<uint8_t> have_list;
+    if (use_lists) lists.resize((size_t)tiles_x * tiles_y * TILE_LIST_WORDS), have_list.assign((size_t)tiles_x * tiles_y, 0);
+    g_list_rays = g_list_tests = g_walk_tiles = g_list_tiles = 0;
     for (uint32_t y = y0; y < y1; y++)
         for (uint32_t x = x0; x < x1; x++) {
             float* texel = accum + 4ull * ((uint64_t)y * w + x);
+            const uint32_t* rec = nullptr;
+            if (use_lists) {
+                const size_t tile = (size_t)(y >> 3) * tiles_x + (x >> 3);
+                uint32_t* r = lists.data() + tile * TILE_LIST_WORDS;
+                if (!have_list[tile]) {
+                    tile_list_build(mem, L, cam64v, x >> 3, y >> 3, w, h, g_tile_list_max, r);
+                    have_list[tile] = 1;
+                    (r[0] == TILE_LIST_WALK ? g_walk_tiles : g_list_tiles)++;
+                }
+                if (r[0] != TILE_LIST_WALK) rec = r;
+            }
             const uint32_t hash = pixel_hash(x, y, w, h);
             for (uint32_t f = 0; f < n_frames; f++) {
                 PathState ps;
@@ -115,7 +140,13 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                         Hit hit;
                         HostStack st;
                         cnt = Counters{0, 0, 0};
-                        if (g_brute_force) {  // every sphere, no boxes: what no tree can change
+                        if (rec && ps.bounce == 0) {  // camera ray: its tile's candidates, no tree
+                            Walk w;
+                            walk_begin<false>(w, L, ps.o, ps.d);
+                            walk_tile_list<PtrMem, true>(mem, L, w, ps.o, ps.d, rec, cnt);
+                            walk_result(w, hit);
+                            g_list_rays++, g_list_tests += cnt.tests;
+                        } else if (g_brute_force) {  // every sphere, no boxes: what no tree can change
                             Walk w;
                             walk_begin<false>(w, L, ps.o, ps.d);
                             for (uint32_t si = 0; si < L.n_spheres; si++) {
