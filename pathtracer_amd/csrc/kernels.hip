@@ -517,6 +517,13 @@ __device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32
 #ifndef PT_LEAF_UNROLL
 #define PT_LEAF_UNROLL 1
 #endif
+// 1: the restart step repeats while enough lanes want it again (camera rays served by candidate lists)
+#ifndef PT_RESTART_LOOP
+#define PT_RESTART_LOOP 0
+#endif
+#ifndef PT_RESTART_LOOP_MIN
+#define PT_RESTART_LOOP_MIN 48u
+#endif
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
 // The kernel's arguments as they lie in the kernarg segment, for the parts of a kernel that run rarely (the
@@ -615,6 +622,22 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             o4.w = 0.0f;
             store_result(P, out_index, o4, rays, lane_rays);
             w.cur = LANE_IDLE;
+        }
+    };
+    // A lane whose walk has ended fetches the material word of its hit and moves to its scatter class.
+    auto classify = [&]() {
+        if (w.cur == WALK_FINISHED) {
+            Hit hit;
+            walk_result(w, hit);
+            mbits = hit_material(mem, P.L, hit);
+            const uint32_t cls = scatter_class(mbits, hit.back);
+            w.cur = cls == SC_OPAQUE ? LANE_OPAQUE : (cls == SC_GLASS ? LANE_GLASS : LANE_TERMINAL);
+            if (COUNT) {
+                const uint32_t type = mbits & 7u;
+                const uint32_t slot = type == MAT_SKY ? 4u : type;  // unknown (4) is not counted
+#pragma unroll
+                for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (slot == k && type != MAT_UNKNOWN) ? 1u : 0u;
+            }
         }
     };
     uint32_t waiting = 0;  // lanes counted by the last call of wants()
@@ -770,19 +793,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         // 20.95 -> 20.70 ms; asking for 8 or 16 lanes more than the node threshold: no gain).
         if (!force && (uint32_t)__popcll(__ballot(walk_is_node(w.cur))) >= P.thr[PH_NODE]) continue;
         // ---- finished walks: fetch the material word and sort the lane into its scatter class
-        if (w.cur == WALK_FINISHED) {
-            Hit hit;
-            walk_result(w, hit);
-            mbits = hit_material(mem, P.L, hit);
-            const uint32_t cls = scatter_class(mbits, hit.back);
-            w.cur = cls == SC_OPAQUE ? LANE_OPAQUE : (cls == SC_GLASS ? LANE_GLASS : LANE_TERMINAL);
-            if (COUNT) {
-                const uint32_t type = mbits & 7u;
-                const uint32_t slot = type == MAT_SKY ? 4u : type;  // unknown (4) is not counted
-#pragma unroll
-                for (uint32_t k = 0; k < 5; k++) bounce_cnt[k] += (slot == k && type != MAT_UNKNOWN) ? 1u : 0u;
-            }
-        }
+        classify();
         // ---- restart, first half (exchange variant): close the paths that end here, then fill idle lanes from a
         // pool that holds enough paths of one scatter class; the scatter steps below then run them (a batch is at
         // least as large as the class's threshold: the host sees to pool_min >= thr)
@@ -848,11 +859,15 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         if constexpr (!XCHG) do_restart = wants(lane_wants_restart(w.cur), PH_IDLE);
         if (do_restart) {
             ran = true;
-            if constexpr (!XCHG) {
+            KernargView Q = kernarg_view();  // what only this step needs is read here (see kernarg_view)
+            // The step repeats while enough lanes want it again: camera rays that test a candidate list (below) know
+            // their hit at once, and those that end there -- sky, a light: four paths in ten of scene1 -- are closed
+            // and replaced in the next pass, without a trip through the scheduler.
+            for (bool again = !XCHG;; again = true) {
+            if (again) {
                 if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
                 if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
             }
-            KernargView Q = kernarg_view();  // what only this step needs is read here (see kernarg_view)
             uint32_t pxy_step = 0;
             uint32_t& pxy_now = FAST ? pxy_step : pxy;  // with one sample per path a lane gets its camera ray in this very step
             unsigned long long m = __ballot(w.cur == LANE_IDLE);
@@ -963,6 +978,14 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         }
                     }
                 }
+            }
+            if constexpr (SCENE == SCENE_REFERENCE || PT_RESTART_LOOP == 0) break;
+            if (!Q->tile_lists) break;
+            classify();  // only camera rays served by a list are in that state here
+            if (exhausted) break;
+            const uint32_t n_again = (uint32_t)__popcll(__ballot(lane_wants_restart(w.cur)));
+            if (n_again < PT_RESTART_LOOP_MIN) break;  // not the forced threshold: a forced round must not keep the other lanes waiting
+            if (COUNT) ph_exec[PH_IDLE]++, ph_lanes[PH_IDLE] += n_again;
             }
         }
         if (!ran) {
