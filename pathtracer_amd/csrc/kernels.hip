@@ -517,13 +517,6 @@ __device__ __forceinline__ bool lane_wants_restart(int32_t cur) { return (uint32
 #ifndef PT_LEAF_UNROLL
 #define PT_LEAF_UNROLL 1
 #endif
-// 1: the restart step repeats while enough lanes want it again (camera rays served by candidate lists)
-#ifndef PT_RESTART_LOOP
-#define PT_RESTART_LOOP 0
-#endif
-#ifndef PT_RESTART_LOOP_MIN
-#define PT_RESTART_LOOP_MIN 48u
-#endif
 enum { PH_NODE = 0, PH_LEAF, PH_TERMINAL, PH_OPAQUE, PH_GLASS, PH_IDLE, PH_COUNT };
 
 // The kernel's arguments as they lie in the kernarg segment, for the parts of a kernel that run rarely (the
@@ -860,11 +853,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         if (do_restart) {
             ran = true;
             KernargView Q = kernarg_view();  // what only this step needs is read here (see kernarg_view)
-            // The step repeats while enough lanes want it again: camera rays that test a candidate list (below) know
-            // their hit at once, and those that end there -- sky, a light: four paths in ten of scene1 -- are closed
-            // and replaced in the next pass, without a trip through the scheduler.
-            for (bool again = !XCHG;; again = true) {
-            if (again) {
+            if constexpr (!XCHG) {
                 if (__ballot(w.cur == LANE_TERMINAL)) t_progress = __builtin_amdgcn_s_memrealtime();
                 if (w.cur == LANE_TERMINAL) finish_sample(scatter_terminal(mem, P.L, mbits, ps));
             }
@@ -978,14 +967,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         }
                     }
                 }
-            }
-            if constexpr (SCENE == SCENE_REFERENCE || PT_RESTART_LOOP == 0) break;
-            if (!Q->tile_lists) break;
-            classify();  // only camera rays served by a list are in that state here
-            if (exhausted) break;
-            const uint32_t n_again = (uint32_t)__popcll(__ballot(lane_wants_restart(w.cur)));
-            if (n_again < PT_RESTART_LOOP_MIN) break;  // not the forced threshold: a forced round must not keep the other lanes waiting
-            if (COUNT) ph_exec[PH_IDLE]++, ph_lanes[PH_IDLE] += n_again;
             }
         }
         if (!ran) {
