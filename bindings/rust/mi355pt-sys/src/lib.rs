@@ -56,6 +56,8 @@ pub struct mi355pt_stats {
     pub node_format: u32,
     pub exchange_on: u32,
     pub exchange: [u64; 4],
+    pub list_tiles: u32,
+    pub list_candidates: u32,
 }
 
 extern "C" {

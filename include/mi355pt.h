@@ -91,6 +91,9 @@ typedef struct mi355pt_stats {
     uint32_t exchange_on;  /* 1 when the last launch ran the kernel variant that exchanges waiting paths between waves */
     uint64_t exchange[4];  /* that variant: pool deposits, lanes deposited, withdrawals, lanes withdrawn
                               (MI355PT_FLAG_COUNT only) */
+    uint32_t list_tiles;      /* 8x8 pixel tiles whose camera rays tested a per-tile candidate list instead of walking
+                                 the tree in the last launch (0: every camera ray walked) */
+    uint32_t list_candidates; /* spheres on those lists, all tiles together */
 } mi355pt_stats;
 
 /* ---- context: Renderer::new / drop (mod.rs:106-146) ---------------------------------------- */
@@ -139,11 +142,14 @@ int mi355pt_render(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
  * (offline.rs:50-52, main.rs:160-161); mi355pt_render() = mi355pt_render_async() + mi355pt_wait(). */
 int mi355pt_render_async(mi355pt_ctx* ctx, uint32_t n_frames, const uint32_t* seeds);
 int mi355pt_wait(mi355pt_ctx* ctx);
-/* mi355pt_render() for callers that cannot allocate device memory (code under HIP graph capture, tight serving
- * loops, harnesses that forbid hipMalloc): same frames, same bits, but the per-launch results, the seeds, the
- * work-queue counter and the stack spill area live in a static 160 MiB device array of the library instead of
- * buffers the context grows on demand, and the call makes no hipMalloc / hipFree / event creation.  No
- * counterpart in the reference.  Limits (MI355PT_ERR_ARG with a message otherwise): at most 1024 frames per
+/* mi355pt_render() for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc): same frames, same bits, but the per-launch results, the seeds, the work-queue counter and the stack
+ * spill area live in a static 160 MiB device array of the library instead of buffers the context grows on
+ * demand, and the call makes no hipMalloc / hipFree / event creation.  It is an ordinary blocking call (it
+ * copies the seeds up, waits for its launches and reads counters back), so it cannot be recorded into a HIP
+ * graph.  The array is part of the library's code object: every device the process uses holds its 160 MiB from
+ * the moment the library is loaded there, whether or not this entry point is ever called.  No counterpart in
+ * the reference.  Limits (MI355PT_ERR_ARG with a message otherwise): at most 1024 frames per
  * call; one frame of results (12 bytes per pixel of the image rounded up to 8x8 tiles) plus the scene's stack
  * spill area must fit in the array -- 3840x2160 does, with any scene that fits beside it.  Launches are as long
  * as the array allows (6 frames at 1920x1080), so this is slower than mi355pt_render(); it is not timed

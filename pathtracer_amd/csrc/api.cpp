@@ -1,5 +1,6 @@
 // C ABI of libmi355pt.so (see include/mi355pt.h).  Host-side state machine of the reference's
 // `Renderer` (src/renderer/mod.rs:91-320) over the HIP device code in kernels.hip.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -60,7 +61,15 @@ int fail(mi355pt_ctx* ctx, int code, const std::string& msg) {
 // Waits for work queued by mi355pt_render_async and folds its timings / counters into the context.
 int settle(mi355pt_ctx* c) {
     std::string err;
-    if (!gpu::finish(c->dev, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+    if (!gpu::finish(c->dev, c->stats, err)) {
+        // frames that were queued but never added (a launch gave up) do not count: samples(), the divisor of
+        // to_rgb8 / save_png and the seed schedule continue from what the accumulator holds
+        const uint32_t dropped = c->stats.dropped_frames;
+        c->stats.dropped_frames = 0;
+        c->frames -= (int32_t)std::min<uint32_t>(dropped, (uint32_t)std::max(c->frames, 0));
+        c->seed_index -= std::min(dropped, c->seed_index);
+        return fail(c, MI355PT_ERR_DEVICE, err);
+    }
     return MI355PT_OK;
 }
 #define SETTLE_OR_RETURN(c)              \
@@ -322,6 +331,12 @@ int mi355pt_render_static(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* see
         std::string err;
         if (!gpu::render_static(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) {
             const bool arg = err.rfind("render_static:", 0) == 0;  // a size the workspace cannot hold
+            if (!arg && c->stats.dropped_frames && c->stats.dropped_frames < n_frames) {
+                // a launch gave up: the launches before it were added and count
+                c->frames += (int32_t)(n_frames - c->stats.dropped_frames);
+                c->seed_index += n_frames - c->stats.dropped_frames;
+            }
+            c->stats.dropped_frames = 0;
             return fail(c, arg ? MI355PT_ERR_ARG : MI355PT_ERR_DEVICE, err);
         }
         c->frames += (int32_t)n_frames;
@@ -345,7 +360,11 @@ int mi355pt_reduce(mi355pt_ctx* const* ctxs, size_t n, size_t root) {
     return guarded(nullptr, [&]() -> int {
         if (!ctxs || n == 0 || root >= n) return fail(nullptr, MI355PT_ERR_ARG, "reduce: bad arguments");
         for (size_t i = 0; i < n; i++)
-            if (!ctxs[i]) return fail(nullptr, MI355PT_ERR_ARG, "reduce: null context");
+            if (!ctxs[i]) {
+                // readable from the root context when there is one, and from mi355pt_last_error(NULL) in any case
+                if (ctxs[root]) ctxs[root]->error = "reduce: null context";
+                return fail(nullptr, MI355PT_ERR_ARG, "reduce: null context");
+            }
         mi355pt_ctx* r = ctxs[root];
         std::vector<gpu::Device*> devs(n);
         int64_t frames = 0;
@@ -466,6 +485,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
         out->node_format = c->have_scene ? c->layout.node_half : 0u;
         out->exchange_on = c->stats.exchange_on ? 1u : 0u;
         for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
+        out->list_tiles = c->stats.list_tiles, out->list_candidates = c->stats.list_candidates;
         return MI355PT_OK;
     });
 }

@@ -25,6 +25,9 @@ struct RenderStats {
     uint32_t launches = 0;
     uint64_t exchange[4] = {0, 0, 0, 0};  // exchange variant: deposits, lanes deposited, withdrawals, lanes withdrawn [counting only]
     bool exchange_on = false;             // the last launch ran the exchange variant
+    uint32_t list_tiles = 0;              // 8x8 tiles whose camera rays test a candidate list in the last launch (0: all walk)
+    uint32_t list_candidates = 0;         // entries of those lists
+    uint32_t dropped_frames = 0;          // set by finish() when it fails: queued frames that were never added to the accumulator
 };
 
 struct RenderConfig {

@@ -41,7 +41,7 @@ struct Switches {
     long stack_lds = 5;         // MI355PT_STACK_LDS: stack entries kept in LDS for scenes walked from global memory
     long node_cache_kb = -1;    // MI355PT_NODE_CACHE_KB: node prefix kept in LDS for those scenes (-1: what fits)
     bool tile_order = true;     // MI355PT_TILE_ORDER=0: tiles in row-major order
-    uint32_t chunk = 0;         // MI355PT_CHUNK: largest work-queue chunk in units (0: 32 for LDS scenes, else 4)
+    uint32_t chunk = 0;         // MI355PT_CHUNK: largest work-queue chunk in units (0: 32; 16 for launches shorter than 16 frames of a scene in global memory)
     float chunk_share = 2.0f;   // MI355PT_CHUNK_SHARE
     float chunk_rays = 2600.0f; // MI355PT_CHUNK_RAYS
     bool lockstep = false;      // MI355PT_KERNEL=lockstep: the simple kernel
@@ -94,6 +94,8 @@ struct Device {
     // Candidate lists of the camera rays (pt_tile_lists_kernel): [tiles][TILE_LIST_WORDS], allocated with the
     // accumulator, rebuilt on the render stream when camera, scene or image size changed
     uint32_t* tile_lists = nullptr;
+    uint32_t* list_count = nullptr;  // two words: tiles with a list, entries of all lists (written by the list kernel)
+    bool lists_in_use = false;       // the last launch read the lists
     bool lists_valid = false;
     Camera64 lists_cam{};
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()
@@ -106,8 +108,13 @@ struct Device {
     std::vector<Timed> timed;          // launches enqueued since the last finish(), both events recorded
     std::vector<hipEvent_t> event_pool;
     bool in_flight = false;
-    uint64_t pending_paths = 0;
-    uint32_t pending_launches = 0;
+    // queued launches in order: frames and paths of each, credited by finish() once their results have been added
+    struct Pending {
+        uint32_t frames;
+        uint64_t paths;
+    };
+    std::vector<Pending> pending;
+    unsigned long long added_seen = 0;  // launches the accumulation kernel had added at the last finish() (counters[9])
     int32_t* stack_spill = nullptr;  // deep traversal-stack entries of scenes walked from global memory
     size_t spill_cap = 0;            // in entries
     uint32_t* work_counter = nullptr;  // [1]

@@ -37,10 +37,10 @@ namespace gpu {
 // RenderParams::chunk_max units while plenty of work is left and shrink towards the end of the queue,
 // where balance matters: chunk = what is left / (2 * waves), clamped to [1, chunk_max]; once tile costs
 // are known, a chunk is also limited to about 2 600 rays (rank_chunk), because the expensive tiles come
-// first and a 32-unit chunk of them keeps one wave busy for 6 ms.  The host sets
-// chunk_max to 32 for scenes in LDS and to 4 for scenes in global memory: there the waves should stay
-// close together in the image, so that the part of the tree they walk stays in the caches (10 M spheres
-// at 3840x2160: 13.0 ms per 8 frames with 4-unit chunks, 28 ms with 32-unit chunks).
+// first and a 32-unit chunk of them keeps one wave busy for 6 ms.  The host sets chunk_max to 32 (16 for short
+// launches of scenes in global memory, see enqueue_in): consecutive units are consecutive frames of one tile, so
+// a wave that keeps a tile for many frames finds the part of a large tree it walks in the caches it has just
+// filled.
 __device__ __forceinline__ uint32_t guided_chunk_units(uint32_t total, uint32_t taken_to, float inv_share,
                                                        uint32_t chunk_max) {
     const uint32_t left = total - min(total, taken_to);
@@ -76,7 +76,7 @@ struct LdsMem {
     }
     __device__ __forceinline__ void node32(uint32_t off, u4& a, u4& b) const { a = load<u4>(off), b = load<u4>(off + 16); }
 };
-// The same with the node section replaced by direction-ordered 80-byte records (LDS_NODE_BYTES) at
+// The same with the node section replaced by direction-ordered 80-byte records, LDS_NODE_BYTES = 88 bytes apart, at
 // `node_base`; `base` is shifted so that the blob offsets of the other sections still apply.  Links to
 // interior nodes are the LDS byte addresses of their records (stage_scene rewrites them), which saves
 // the address arithmetic per visit; LDS addresses are small positive numbers, leaf links stay negative.
@@ -265,7 +265,7 @@ __global__ void pt_hash_kernel(uint32_t* out, uint32_t w, uint32_t h) {
 // Candidate lists of the camera rays, one thread per 8x8 tile (tile_list_build): once per camera, scene and image
 // size.  Reads the blob in global memory whatever the path kernels stage in LDS.
 __global__ void pt_tile_lists_kernel(const char* scene, SceneLayout L, Camera64 cam, uint32_t width, uint32_t height,
-                                     uint32_t tiles_x, uint32_t tiles, uint32_t max_list, uint32_t* lists) {
+                                     uint32_t tiles_x, uint32_t tiles, uint32_t max_list, uint32_t* lists, uint32_t* count) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= tiles) return;
     PtrMem mem{scene};
@@ -275,6 +275,7 @@ __global__ void pt_tile_lists_kernel(const char* scene, SceneLayout L, Camera64 
     typedef uint32_t w4 __attribute__((ext_vector_type(4)));
     w4* out = reinterpret_cast<w4*>(lists + (size_t)t * TILE_LIST_WORDS);
     for (uint32_t k = 0; k < TILE_LIST_WORDS / 4u; k++) out[k] = w4{rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]};
+    if (rec[0] != TILE_LIST_WALK) atomicAdd(count, 1u), atomicAdd(count + 1, rec[0]);  // statistics only
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -295,7 +296,7 @@ template <> struct SceneMem<SCENE_LDS> { typedef LdsOrderedMem type; };
 template <> struct SceneMem<SCENE_LDS_HALF> { typedef LdsMem type; };
 
 // Copies what the workgroup keeps in LDS: the whole blob (LDS scenes; float nodes become
-// direction-ordered 80-byte records on the way) or the node prefix (global scenes).
+// direction-ordered records, LDS_NODE_BYTES apart, on the way) or the node prefix (global scenes).
 template <int SCENE, int BLK>
 __device__ __forceinline__ void stage_scene(const RenderParams& P, uint32_t lds0) {
     typedef uint32_t w4 __attribute__((ext_vector_type(4)));
@@ -650,18 +651,24 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     uint32_t x_dep = 0, x_dep_lanes = 0, x_wd = 0, x_wd_lanes = 0;
     [[maybe_unused]] const uint32_t pool = lds0 + P.pool_off;
     auto pool_word = [&](uint32_t off) { return reinterpret_cast<PT_LDS(uint32_t)*>(pool + off); };
-    auto pool_lock = [&](uint32_t cls) {  // lane 0 only; the holder never waits for anything, so this ends
+    // Lane 0 only; the holder never waits for anything, so this ends.  False when the lock could not be had (a bug
+    // must end the launch, not hang the GPU): flagged like a watchdog expiry -- the launch's results are discarded --
+    // and the caller stays out of the critical section and makes the wave leave the scheduler loop (`abandon`).
+    bool abandon = false;  // wave-uniform
+    auto pool_lock = [&](uint32_t cls) -> bool {
         uint32_t expected = 0u, spins = 0u;
         while (!__hip_atomic_compare_exchange_strong(pool_word(cls * 8u), &expected, 1u, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_WORKGROUP)) {
             expected = 0u;
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 22)) {  // a bug must end the launch, not hang the GPU: flag it like the watchdog does
+            if (++spins > (1u << 22)) {
                 atomicAdd(&P.counters[10], 1ull);
-                break;
+                return false;
             }
         }
+        return true;
     };
+    constexpr uint32_t NO_ROOM = 0xffffffffu, NO_LOCK = 0xfffffffeu;
     auto pool_unlock = [&](uint32_t cls) {
         __hip_atomic_store(pool_word(cls * 8u), 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     };
@@ -673,15 +680,21 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     auto deposit = [&](uint32_t cls, bool mine) -> bool {
         const unsigned long long m = __ballot(mine);
         const uint32_t n = (uint32_t)__popcll(m);
-        uint32_t base = 0xffffffffu;
+        uint32_t base = NO_ROOM;
         if (lane == 0) {
-            pool_lock(cls);
-            const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (c + n <= POOL_CAP) base = c;
-            else pool_unlock(cls);
+            if (pool_lock(cls)) {
+                const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (c + n <= POOL_CAP) base = c;
+                else pool_unlock(cls);
+            } else {
+                base = NO_LOCK;
+            }
         }
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (base == 0xffffffffu) return false;
+        if (base >= NO_LOCK) {
+            if (base == NO_LOCK) abandon = true;
+            return false;
+        }
         if (mine) {
             // one word per store, straight from the registers the values live in (16-byte stores would need them
             // copied into aligned register quads first: vector instructions, the scarce kind here)
@@ -712,16 +725,22 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         if (k == 0u) return false;
         uint32_t base = 0u, take = 0u;
         if (lane == 0) {
-            pool_lock(cls);
-            const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            take = c >= wmin ? min(c, k) : 0u;
-            base = c - take;
-            if (take) __hip_atomic_store(pool_word(cls * 8u + 4u), base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else pool_unlock(cls);
+            if (pool_lock(cls)) {
+                const uint32_t c = __hip_atomic_load(pool_word(cls * 8u + 4u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                take = c >= wmin ? min(c, k) : 0u;
+                base = c - take;
+                if (take) __hip_atomic_store(pool_word(cls * 8u + 4u), base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else pool_unlock(cls);
+            } else {
+                base = NO_LOCK;
+            }
         }
         take = (uint32_t)__builtin_amdgcn_readfirstlane((int)take);
         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        if (take == 0u) return false;
+        if (take == 0u) {
+            if (base == NO_LOCK) abandon = true;
+            return false;
+        }
         const uint32_t rank = lane_rank(m);
         if (free_lane && rank < take) {
             const uint32_t a = pool + POOL_HEADER + cls * (POOL_CAP * 64u) + (base + rank) * 4u;
@@ -748,6 +767,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         if ((round & 1023u) == 1023u && __builtin_amdgcn_s_memrealtime() - t_progress > P.watchdog_ticks) {
             if (lane == 0) atomicAdd(&P.counters[10], 1ull);
             break;
+        }
+        if constexpr (XCHG) {
+            if (abandon) break;  // a pool lock could not be had: the pools are not to be trusted, the launch is void
         }
         bool ran = false;
         // ---- interior nodes: keep stepping while enough lanes have one pending
@@ -869,8 +891,8 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         // the waves of a compute unit then work on the same few tiles.  State in the pool header:
                         // lock, next unit, end (both ~0 once the queue has been seen empty).
                         uint32_t got = 0;
-                        if (lane == 0) {
-                            pool_lock(4u);
+                        if (lane == 0 && !pool_lock(4u)) got = NO_LOCK;
+                        if (lane == 0 && got != NO_LOCK) {
                             uint32_t n = __hip_atomic_load(pool_word(36u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             uint32_t e = __hip_atomic_load(pool_word(40u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             if (n >= e && n != 0xffffffffu) {
@@ -886,8 +908,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         }
                         base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
                         got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-                        if (got == 0u) {
+                        if (got == 0u || got == NO_LOCK) {
                             exhausted = true;
+                            abandon = got == NO_LOCK;
                             break;
                         }
                         next = base * 64u;
@@ -1023,11 +1046,12 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
 __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
                                   uint32_t tiles, uint32_t n_frames, const uint32_t* tile_perm,
                                   unsigned long long* ray_total, float* tile_cost, uint32_t compact,
-                                  const unsigned long long* gave_up) {
+                                  const unsigned long long* gave_up, unsigned long long* launches_added) {
     // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
     // so nothing of this launch is added.
     if (*gave_up) return;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid == 0) atomicAdd(launches_added, 1ull);  // what finish() credits: launches whose results reached the accumulator
     const uint32_t rank = gid >> 6, slot = gid & 63u;
     unsigned long long rays = 0;
     uint32_t tile = 0;
@@ -1168,8 +1192,8 @@ static void read_switches(Switches& s) {
     }
 }
 
-// Static workspace of render_static(): callers that cannot allocate (code under graph capture, tight serving
-// loops, harnesses that forbid hipMalloc) render with the frame buffer, the seeds, the work-queue counter and
+// Static workspace of render_static(): callers that cannot allocate (tight serving loops, harnesses that forbid
+// hipMalloc) render with the frame buffer, the seeds, the work-queue counter and
 // the stack spill area in this array instead of in buffers the context grows on demand.  Every device the
 // library runs on holds its own copy at its own address until the process ends.  In host code the array's
 // name is only a handle for hipGetSymbolAddress; kernels and memsets get the looked-up address.
@@ -1234,7 +1258,7 @@ bool create(int device_id, void* stream, Device** out, std::string& err) {
         d->own_stream = true;
     }
     if (hipMalloc(&d->work_counter, 256) != hipSuccess || hipMalloc(&d->counters, COUNTER_BYTES) != hipSuccess ||
-        hipMalloc(&d->ray_slots, RAY_SLOTS * RAY_SLOT_STRIDE * 8) != hipSuccess) {
+        hipMalloc(&d->ray_slots, RAY_SLOTS * RAY_SLOT_STRIDE * 8) != hipSuccess || hipMalloc(&d->list_count, 256) != hipSuccess) {
         destroy(d);
         err = "hipMalloc failed";
         return false;
@@ -1264,6 +1288,7 @@ void destroy(Device* d) {
     (void)hipFree(d->tile_perm);
     (void)hipFree(d->rank_chunk);
     (void)hipFree(d->tile_lists);
+    (void)hipFree(d->list_count);
     (void)hipFree(d->seeds);
     (void)hipFree(d->stack_spill);
     (void)hipFree(d->work_counter);
@@ -1399,6 +1424,7 @@ bool clear(Device* d, std::string& err) {
                        v);
     PT_HIP(hipGetLastError());
     PT_HIP(hipMemsetAsync(d->counters, 0, COUNTER_BYTES, d->stream));
+    d->added_seen = 0;
     PT_HIP(hipMemsetAsync(d->ray_slots, 0, RAY_SLOTS * RAY_SLOT_STRIDE * 8, d->stream));
     PT_SYNC_ALL(d);
     return true;
@@ -1506,8 +1532,7 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
             d->seed_staging.clear();
             d->seeds_head = 0;
             d->in_flight = false;
-            d->pending_paths = 0;
-            d->pending_launches = 0;
+            d->pending.clear();
         }
     } reset{d};
     PT_SYNC_ALL(d);
@@ -1530,11 +1555,24 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
         stats.rays = 0;
         for (uint32_t k = 0; k < RAY_SLOTS; k++) stats.rays += slots[(size_t)k * RAY_SLOT_STRIDE];
     }
-    stats.paths += d->pending_paths;
-    stats.launches += d->pending_launches;
+    stats.list_tiles = stats.list_candidates = 0;
+    if (d->lists_in_use) {
+        uint32_t lc[2];
+        PT_HIP(hipMemcpy(lc, d->list_count, sizeof lc, hipMemcpyDeviceToHost));
+        stats.list_tiles = lc[0], stats.list_candidates = lc[1];
+    }
+    // The accumulation kernel counts the launches it has added (counters[9]); it skips a launch whose path kernel
+    // gave up and every later one that was already queued, so the accumulator holds exactly the first `added` of
+    // the queued launches, and only those are credited.
+    const size_t added = std::min<size_t>(d->pending.size(), (size_t)(host_counters[9] - d->added_seen));
+    d->added_seen = host_counters[9];
+    stats.dropped_frames = 0;
+    for (size_t k = 0; k < d->pending.size(); k++) {
+        if (k < added) stats.paths += d->pending[k].paths, stats.launches++;
+        else stats.dropped_frames += d->pending[k].frames;
+    }
     if (host_counters[10]) {
-        // Reported once.  The accumulation kernel skips a launch whose path kernel gave up (and every later one
-        // that was already queued), so the accumulator holds exactly the launches that completed before it.
+        // Reported once.
         PT_HIP(hipMemset(d->counters + 10, 0, 8));
         err = "render: kernel watchdog expired (" + std::to_string(host_counters[10]) +
               " waves gave up); the frames of that launch and of the launches queued behind it were not added";
@@ -1581,7 +1619,9 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     // 32.4 ms, 2 launches 30.3 ms, 1 launch 29.0 ms.
     uint32_t batch = cfg.max_batch ? cfg.max_batch : sw.max_batch;
     if (fixed) {
-        batch = 0xffffffffu;  // bounded below by what the area holds, once the spill area is known
+        // What the area holds if no spill space is needed; the launch is shaped (workgroup size, queue chunks,
+        // exchange variant) for this length, and clamped further below once the spill area is known.
+        batch = (uint32_t)std::max<size_t>(1, std::min<size_t>(fixed->frame_bytes / ((size_t)tiles * 64u * 12u), 4096));
     } else if (batch == 0) {
         size_t budget = FRAME_BUF_DEFAULT_BYTES;
         if (sw.frame_buf_gb) {
@@ -1769,10 +1809,13 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     // Candidate lists of the camera rays: rebuilt on the stream, ahead of the launches that read them, when the
     // camera, the scene or the image size changed (no allocation: the buffer came with the accumulator).  The
     // reference-walk mode tries exactly the spheres the reference's walk tries, so it keeps the walk.
+    d->lists_in_use = false;
     if (sw.tile_lists && !lockstep && !d->layout.reference_walk && d->tile_lists) {
+        d->lists_in_use = true;
         if (!d->lists_valid || memcmp(&cam, &d->lists_cam, sizeof cam) != 0) {
+            PT_HIP(hipMemsetAsync(d->list_count, 0, 8, d->stream));
             hipLaunchKernelGGL(pt_tile_lists_kernel, dim3((tiles + 63u) / 64u), dim3(64), 0, d->stream, d->scene, d->layout, cam,
-                               d->width, d->height, tiles_x, tiles, sw.tile_list_max, d->tile_lists);
+                               d->width, d->height, tiles_x, tiles, sw.tile_list_max, d->tile_lists, d->list_count);
             PT_HIP(hipGetLastError());
             d->lists_valid = true;
             d->lists_cam = cam;
@@ -1846,7 +1889,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         if (!timed_launch(true, [&]() {
                 hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
                                    P.frame_out, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
-                                   measure ? d->tile_cost : nullptr, P.compact, d->counters + 10);
+                                   measure ? d->tile_cost : nullptr, P.compact, d->counters + 10, d->counters + 9);
                 PT_HIP(hipGetLastError());
                 return true;
             }))
@@ -1864,8 +1907,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
             d->since_measure++;
         }
         stats.exchange_on = P.pool_off != 0u;
-        d->pending_launches++;
-        d->pending_paths += (uint64_t)d->n_pix * (uint64_t)cfg.samples * nb;
+        d->pending.push_back(Device::Pending{nb, (uint64_t)d->n_pix * (uint64_t)cfg.samples * nb});
     }
     return true;
 }

@@ -151,7 +151,10 @@ def reduce(renderers, root=0):
     arr = (C.c_void_p * len(renderers))(*[r._ctx for r in renderers])
     rc = lib().mi355pt_reduce(arr, len(renderers), int(root))
     if rc != 0:
-        raise Mi355ptError(rc, lib().mi355pt_last_error(renderers[root]._ctx).decode(errors="replace"))
+        # failures that name no context (bad root, empty list) are kept per thread, not on a context
+        ctx = renderers[root]._ctx if 0 <= int(root) < len(renderers) else None
+        msg = lib().mi355pt_last_error(ctx) if ctx else b""
+        raise Mi355ptError(rc, (msg or lib().mi355pt_last_error(None) or b"").decode(errors="replace"))
 
 
 def frame_seed(base_seed, frame):

@@ -99,6 +99,25 @@ def emul():
         return acc, dict(zip(names, [int(c) for c in cnt])), [int(i) for i in info]
 
     L.render = render
+
+    def tile_lists(sc, cam, W, H, max_list=15):
+        """(lists[tiles_y, tiles_x, 16], order[n_spheres]): word 0 = count or 0xffffffff (keep the walk), then
+        leaf-order sphere indices; order maps those to the scene's own sphere indices."""
+        ty, tx = (H + 7) // 8, (W + 7) // 8
+        out = np.zeros((ty, tx, 16), np.uint32)
+        order = np.zeros(len(sc.spheres), np.uint32)
+        cam = np.ascontiguousarray(cam, np.float32)
+        vp, sz = C.c_void_p, C.c_size_t
+        r = L.emul_tile_lists(vp(sc.spheres.ctypes.data), sz(len(sc.spheres)), vp(sc.lights.ctypes.data),
+                              sz(len(sc.lights)), vp(sc.lambertians.ctypes.data), sz(len(sc.lambertians)),
+                              vp(sc.metals.ctypes.data), sz(len(sc.metals)), vp(sc.glass.ctypes.data), sz(len(sc.glass)),
+                              vp(cam.ctypes.data), C.c_uint32(W), C.c_uint32(H), C.c_uint32(max_list),
+                              vp(out.ctypes.data), vp(order.ctypes.data))
+        if r != 0:
+            raise RuntimeError(L.emul_error().decode())
+        return out, order
+
+    L.tile_lists = tile_lists
     return L
 
 

@@ -244,6 +244,37 @@ int emul_check_top_first(const void* spheres32, size_t n, uint32_t k_top) {
     return 0;
 }
 
+// Candidate lists of every 8x8 tile (tile_list_build, the code of the device's list kernel) over the SAH tree of
+// the scene: out[tiles][TILE_LIST_WORDS]; order_out (n_spheres, optional) receives the caller's sphere index of
+// every leaf-order index the lists use.
+int emul_tile_lists(const void* spheres32, size_t n_spheres, const void* lights, size_t n_lights, const void* lamb,
+                    size_t n_lamb, const void* metals, size_t n_metals, const void* glass, size_t n_glass, const void* cam64,
+                    uint32_t w, uint32_t h, uint32_t max_list, uint32_t* out, uint32_t* order_out) {
+    SceneArrays a;
+    a.spheres = (const Sphere32*)spheres32, a.n_spheres = n_spheres;
+    a.lights = (const Vec16*)lights, a.n_lights = n_lights;
+    a.lambertians = (const Vec16*)lamb, a.n_lambertians = n_lamb;
+    a.metals = (const Vec16*)metals, a.n_metals = n_metals;
+    a.glass = (const float*)glass, a.n_glass = n_glass;
+    std::vector<char> blob;
+    SceneLayout L;
+    Bvh2 bvh;
+    if (!pack_scene(a, false, nullptr, 0, blob, L, bvh, g_err)) return -1;
+    PtrMem mem{blob.data()};
+    Camera64 cam;
+    memcpy(&cam, cam64, 64);
+    const uint32_t tiles_x = (w + 7u) / 8u, tiles_y = (h + 7u) / 8u;
+    for (uint32_t ty = 0; ty < tiles_y; ty++)
+        for (uint32_t tx = 0; tx < tiles_x; tx++) {
+            uint32_t* rec = out + ((size_t)ty * tiles_x + tx) * TILE_LIST_WORDS;
+            for (uint32_t k = 0; k < TILE_LIST_WORDS; k++) rec[k] = 0u;
+            tile_list_build(mem, L, cam, tx, ty, w, h, max_list, rec);
+        }
+    if (order_out)
+        for (size_t i = 0; i < n_spheres; i++) order_out[i] = bvh.order[i];
+    return 0;
+}
+
 uint32_t emul_pixel_hash(uint32_t px, uint32_t py, uint32_t w, uint32_t h) { return pixel_hash(px, py, w, h); }
 float emul_det_sin(float x) { return det_sin(x); }
 

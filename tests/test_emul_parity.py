@@ -272,3 +272,60 @@ def test_reference_walk_follows_the_reference_where_trees_matter(emul, orc, pa, 
     assert bits_equal(ref, acc) and cnt["rays"] == st["rays"]
     # the same spheres are tried: interior visits differ by construction, sphere tests do not
     assert cnt["tests"] == st["leaf_visits"]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_camera_ray_candidate_lists_change_no_bit(emul, pa, orc, seed):
+    # camera rays that test their tile's candidate list (tile_list_build, the device's default) find the hits the
+    # tree walk finds: same accumulator, same rays, whatever the longest list allowed; with lists off every camera
+    # ray walks; a list never holds more candidates than allowed
+    sc = random_scene(pa, 7000 + seed)
+    osc = oracle_scene(orc, sc)
+    W, H = 52, 37   # ragged: tiles cut by the right and the lower edge
+    cam = osc.camera(W, H)
+    ref, st = orc.render(osc, cam, W, H, SEEDS[:2], threads=4)
+    try:
+        emul.emul_set_tile_lists(0, 15)
+        walk, cnt_w, _ = emul.render(sc, cam, W, H, SEEDS[:2])
+        assert emul.tile_list_stats()["list_rays"] == 0
+        assert bits_equal(ref, walk) and cnt_w["rays"] == st["rays"]
+        served = []
+        for max_list in (15, 3, 1, 0):
+            emul.emul_set_tile_lists(1, max_list)
+            acc, cnt, _ = emul.render(sc, cam, W, H, SEEDS[:2])
+            s = emul.tile_list_stats()
+            assert bits_equal(ref, acc) and cnt["rays"] == st["rays"], max_list
+            assert s["list_tests"] <= s["list_rays"] * max_list
+            assert s["list_tiles"] + s["walk_tiles"] == ((W + 7) // 8) * ((H + 7) // 8)
+            served.append(s["list_rays"])
+        assert served == sorted(served, reverse=True)   # shorter limits serve fewer rays
+    finally:
+        emul.emul_set_tile_lists(1, 15)
+
+
+def test_candidate_lists_hold_every_sphere_a_camera_ray_hits(emul, pa, orc):
+    # soundness of the cone cull, checked against the oracle's own primary hits: the sphere the reference's walk
+    # finds for a camera ray is among the candidates of the ray's tile (scene1: every tile has a list)
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    osc = orc.Scene.from_ron(os.path.join(FIXTURES, "scene1.ron"))
+    W, H = 320, 180
+    cam = osc.camera(W, H)
+    lists, order = emul.tile_lists(sc, cam, W, H)
+    counts = lists[..., 0]
+    assert (counts != 0xFFFFFFFF).all() and counts.max() <= 15
+    assert (counts == 0).any() and (counts > 1).any()   # sky tiles and tiles with several candidates exist
+    # all-light variant of the scene: a pixel then shows the colour of the sphere its camera ray hits first
+    n = len(sc.spheres)
+    from pathtracer_amd.renderer import VEC16_DT, Scene
+    sp = sc.spheres.copy()
+    sp["mat_type"], sp["mat_index"] = 0, np.arange(n)
+    lights = np.zeros(n, VEC16_DT)
+    lights["v"][:, 0] = np.arange(n) + 1.0    # exact in binary32: red channel = sphere index + 1
+    probe = Scene(sc.camera, sp, lights, sc.lambertians, sc.metals, sc.glass)
+    acc, _ = orc.render(oracle_scene(orc, probe), cam, W, H, [5], threads=4)
+    hit = acc[..., 0].astype(np.int64) - 1     # -1: sky (its red is below 1)
+    for y in range(H):
+        for x in range(W):
+            if hit[y, x] >= 0:
+                rec = lists[y // 8, x // 8]
+                assert hit[y, x] in set(order[rec[1:1 + rec[0]]].tolist()), (x, y)

@@ -483,10 +483,15 @@ def test_watchdog_leaves_the_accumulator_as_it_was(pa, monkeypatch):
         with pytest.raises(pa.Mi355ptError, match="watchdog"):
             r.render(seeds=[1])
         assert bits_equal(cleared, r.read_accum())   # nothing of the abandoned launch was added
+        assert r.samples() == 0 and r.stats()["paths"] == 0   # ... and nothing of it is counted
         with pytest.raises(pa.Mi355ptError, match="watchdog"):
             r.render(seeds=[2])                      # reported per launch, not once and for all
         assert bits_equal(cleared, r.read_accum())
-        assert r.stats()["launches"] >= 2
+        with pytest.raises(pa.Mi355ptError, match="watchdog"):
+            r.render(3, wait=False)                  # queued frames are dropped the same way when the queue is joined
+            r.wait()
+        s = r.stats()
+        assert r.samples() == 0 and s["paths"] == 0 and s["launches"] == 0
     assert np.all(before[..., 3] == 1.0)
 
 
@@ -610,3 +615,56 @@ print("ok")
     from conftest import ROOT
     out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_camera_ray_candidate_lists_are_bit_identical(pa, orc, monkeypatch):
+    # Camera rays test their tile's candidate list instead of walking the tree (pt_tile_lists_kernel, rebuilt when
+    # camera, scene or image size change).  With lists, without, and with lists so short that most tiles keep the
+    # walk, the accumulator equals the oracle's; so it does after a camera move, a resize and a scene reload on one
+    # context, with several samples per path, and for a tree in global memory.
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    W, H, seeds = 200, 117, [21, 22, 23]
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=8)
+    tiles = ((W + 7) // 8) * ((H + 7) // 8)
+    for env, want_tiles in (({}, tiles), ({"MI355PT_TILE_LISTS": "0"}, 0), ({"MI355PT_TILE_LIST_MAX": "1"}, None)):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for flags in (0, pa.FLAG_COUNT):
+            with pa.Renderer(sc, pa.Settings(1, 50), W, H, flags=flags) as r:
+                r.render(seeds=seeds)
+                s = r.stats()
+                assert bits_equal(ref, r.read_accum()) and s["rays"] == st["rays"], env
+                if want_tiles == 0:
+                    assert s["list_tiles"] == 0
+                elif want_tiles:                       # a few tiles of this small image see more than 15 spheres
+                    assert 0.9 * want_tiles < s["list_tiles"] <= want_tiles
+                else:
+                    assert 0 < s["list_tiles"] < tiles and s["list_candidates"] <= s["list_tiles"]
+        for k in env:
+            monkeypatch.delenv(k)
+    # one context: camera move, resize, scene reload, samples > 1
+    other = pa.load_ron_scene(os.path.join(FIXTURES, "scene3.ron"))
+    oother = orc.Scene.from_ron(os.path.join(FIXTURES, "scene3.ron"))
+    with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+        r.render(seeds=seeds)
+        assert bits_equal(ref, r.read_accum())
+        cam = sc.camera
+        moved = pa.CameraSettings((cam.pos[0] + 1.5, cam.pos[1] + 0.5, cam.pos[2] - 2.0), cam.yaw + 30.0, cam.pitch - 5.0, 35.0)
+        r.set_camera_config(moved)
+        r.render(seeds=seeds)
+        def moved_cam(w, h):
+            return orc.camera_build(np.array(moved.pos, np.float32), np.float32(moved.yaw), np.float32(moved.pitch),
+                                    np.float32(moved.vfov), np.float32(w) / np.float32(h))
+        want, _ = orc.render(osc, moved_cam(W, H), W, H, seeds, threads=8)
+        assert bits_equal(want, r.read_accum())
+        r.resize(96, 64)
+        r.render(seeds=seeds[:2])
+        want, _ = orc.render(osc, moved_cam(96, 64), 96, 64, seeds[:2], threads=8)
+        assert bits_equal(want, r.read_accum())
+        r.reload_scene(other)               # the Python mirror also takes the new scene's camera
+        r.reload_settings(pa.Settings(3, 7))
+        r.render(seeds=seeds[:2])
+        want, _ = orc.render(oother, oother.camera(96, 64), 96, 64, seeds[:2], samples=3, depth=7, threads=8)
+        assert bits_equal(want, r.read_accum())
+        assert r.stats()["list_tiles"] == 12 * 8   # scene3: ten spheres, every tile has a list

@@ -78,3 +78,27 @@ def test_static_workspace_limits(pa):
         r.clear()
         r.render(seeds=[5])
         assert bits_equal(a, r.read_accum())
+
+
+def test_static_workspace_call_allocates_no_device_memory(pa):
+    # free device memory as the HIP runtime reports it is the same before and after a render_static call (after
+    # one warm-up call: the first launch of a kernel may load its code object); a plain render of the same frames
+    # in a fresh context grows the context's buffers and shows up in the same reading
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = C.c_size_t(0), C.c_size_t(0)
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return free.value
+
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    seeds = np.arange(7, 19, dtype=np.uint32)
+    with pa.Renderer(sc, pa.Settings(1, 50), 640, 360) as r:
+        r.render_static(seeds=seeds[:2])           # warm-up
+        before = free_bytes()
+        r.render_static(seeds=seeds)
+        r.render_static(seeds=seeds[:5])
+        assert free_bytes() == before
+        r.render(seeds=seeds)                      # control: this one allocates a frame buffer and a seed ring
+        assert free_bytes() < before
