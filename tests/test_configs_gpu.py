@@ -49,6 +49,7 @@ def full_size_properties(pa, orc, sc, W, H, frames, crop, exact=True):
     else:
         differ = (ref[y0:y1, x0:x1].view(np.uint32) != a[y0:y1, x0:x1].view(np.uint32)).any(axis=2)
         assert differ.sum() * 1000 <= differ.size
+    s["accum"], s["oracle_scene"], s["seeds"] = a, osc, seeds
     return s
 
 
@@ -59,13 +60,30 @@ def test_c3_small_scenes_1080p_256_frames(pa, orc, name):
     assert s["scene_in_lds"] == 1
 
 
-def test_c4_million_spheres_4k(pa, orc):
-    # 3840x2160, 64 frames of the 256 (the oracle's crop sets the time); the crop lies below the horizon rows,
-    # where the default tree and the reference's agree bit for bit (see test_million_spheres_within_the_stated_bound)
+def test_c4_million_spheres_4k_256_frames(pa, orc):
+    # The configuration at its stated size: 3840x2160, all 256 frames (four launches), twice (split- and
+    # queue-invariance).  Oracle crop 1: 128x64 texels below the horizon, all 256 frames -- equal bits.  Oracle crop
+    # 2: 64x96 texels across the horizon (rows 600-695; the plane's horizon is near row 650), where the sphere
+    # test's cancellation lets a far, tiny sphere be "hit" by a ray that misses its padded box, so that the spheres a
+    # walk tries decide a sample, in the reference as much as here: after 256 frames a texel differs when any of its
+    # 256 samples did, so the bound is per texel of the crop (<= 1 %, measured 1 of 1536) and on the size of the
+    # difference (one sample of 256).  The reference-walk mode, which is bit-equal there too, takes minutes per 4K
+    # frame at this size and has no way to render a crop: test_million_spheres_within_the_stated_bound checks it
+    # on the whole image at 160x90.
     from pathtracer_amd import synth
     sc = synth.plane_scene(1_000_000)
-    s = full_size_properties(pa, orc, sc, 3840, 2160, 64, (1900, 1932, 1500, 1516), exact=False)
-    assert s["scene_in_lds"] == 0
+    W, H = 3840, 2160
+    s = full_size_properties(pa, orc, sc, W, H, 256, (1900, 2028, 1800, 1864), exact=True)
+    assert s["scene_in_lds"] == 0 and s["launches"] >= 4
+    assert s["list_tiles"] > 0.9 * (W // 8) * (H // 8)        # camera rays of all but the horizon tiles test lists
+    x0, x1, y0, y1 = crop = (1900, 1964, 600, 696)
+    ref, _ = orc.render(s["oracle_scene"], s["oracle_scene"].camera(W, H), W, H, s["seeds"], crop=crop, threads=16)
+    A, R = s["accum"][y0:y1, x0:x1], ref[y0:y1, x0:x1]
+    differ = (A.view(np.uint32) != R.view(np.uint32)).any(axis=2)
+    assert differ.sum() * 100 <= differ.size
+    rel = np.abs(A[..., :3] - R[..., :3]) / np.maximum(1e-3, np.abs(R[..., :3]))
+    assert rel.max() <= 2e-2
+    assert (R[..., :3] > 0).all() and np.unique(R[..., 2]).size > differ.size // 2   # the crop is a real image
 
 
 def run_cli(*args, cwd):
@@ -149,16 +167,18 @@ def test_reduce_over_contexts(pa):
 def test_c5_ten_million_spheres_partitioned_over_eight_contexts(pa):
     # C5 in miniature: the 10 M-sphere scene at 4K, its frames split eight ways by mi355pt_partition_frames
     # (the eight contexts share this box's one device; on an eight-GPU node each would have its own and the sum
-    # would go through RCCL), one mi355pt_reduce to the root.  Against one context that renders every frame only
-    # the order of the float additions differs (bound of the multi-GPU path: 1e-6 relative).  Trees built on the
-    # device: eight host builds of this scene would take a quarter of a minute.
+    # would go through RCCL), one mi355pt_reduce to the root.  256 frames, 32 per context: more than one launch in
+    # the one-context render, and every context measures its tile order inside the partitioned path.  Against one
+    # context that renders every frame only the order of the 256 float additions per texel differs (root mean
+    # square 1e-6 relative; a single texel at most 2e-5, i.e. 256 roundings one way).  Trees built on the device:
+    # eight host builds of this scene would take a quarter of a minute.
     from pathtracer_amd import synth
     sc = synth.plane_scene(10_000_000)
-    W, H, F, N = 3840, 2160, 16, 8
+    W, H, F, N = 3840, 2160, 256, 8      # 32 frames per context: the tile order is measured inside the partitioned path
     with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) as r:
         r.render(F)
         one, st_one = r.read_accum(), r.stats()
-    assert st_one["scene_in_lds"] == 0 and st_one["paths"] == W * H * F
+    assert st_one["scene_in_lds"] == 0 and st_one["paths"] == W * H * F and st_one["launches"] > 1
     rs = [pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) for _ in range(N)]
     try:
         for k, r in enumerate(rs):
@@ -170,7 +190,7 @@ def test_c5_ten_million_spheres_partitioned_over_eight_contexts(pa):
         assert rs[0].samples() == F and st["paths"] == st_one["paths"] and st["rays"] == st_one["rays"]
         assert np.all(acc[..., 3] == 1.0) and np.isfinite(acc).all()
         rel = np.abs(acc[..., :3] - one[..., :3]) / np.maximum(1.0, np.abs(one[..., :3]))
-        assert rel.max() <= 2e-6 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 1e-6
+        assert rel.max() <= 2e-5 and np.sqrt(np.mean(rel.astype(np.float64) ** 2)) <= 1e-6
     finally:
         for r in rs:
             r.close()
