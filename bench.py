@@ -177,8 +177,7 @@ def main():
     def step_seeds(step, rank=rank, world=world):
         # frames [step * step_frames, (step + 1) * step_frames) of one seed schedule, split over the ranks by
         # mi355pt_partition_frames (contiguous blocks): weak scaling gives every rank F of them
-        return parallel.seeds_for(base_seed, parallel.rank_frames(step_frames, rank, world, first=step * step_frames),
-                                  pa.frame_seed)
+        return parallel.seeds_for(base_seed, parallel.step_frames(step, F, rank, world, args.total_frames), pa.frame_seed)
 
     def sync():
         torch.cuda.synchronize()

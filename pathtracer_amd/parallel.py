@@ -18,6 +18,15 @@ def rank_frames(n_frames, rank, world, first=0):
     return range(first + start, first + start + count)
 
 
+def step_frames(step, frames_per_step, rank, world, total_frames=0):
+    """Frames `rank` renders in step `step` of a multi-step run (bench.py): every step covers the next
+    `frames_all` frames of one seed schedule, split over the ranks by rank_frames.  Weak scaling (total_frames == 0):
+    frames_all = frames_per_step * world, so every rank renders frames_per_step of them; strong scaling:
+    frames_all = total_frames whatever the world size (the shape of the 8-GPU configuration)."""
+    frames_all = total_frames if total_frames > 0 else frames_per_step * world
+    return rank_frames(frames_all, rank, world, first=step * frames_all)
+
+
 class _DevicePtr:
     """Minimal __cuda_array_interface__ carrier so torch can wrap memory the library allocated."""
 

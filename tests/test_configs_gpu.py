@@ -222,3 +222,39 @@ def test_reduce_comm_with_a_one_rank_rccl_communicator(pa):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+def test_reduce_comm_between_two_processes(pa, tmp_path):
+    # The one-process-per-GPU shape with the library's own RCCL call: two processes, a two-rank communicator
+    # (ncclGetUniqueId / ncclCommInitRank), each renders its half of ten frames and calls mi355pt_reduce_comm.  This
+    # box has one GPU, so both ranks sit on device 0: if RCCL accepts that, the root's accumulator must equal a
+    # one-process render up to the order of two additions; if it refuses (NCCL's "duplicate GPU" check:
+    # ncclInvalidUsage at communicator set-up, before any kernel), both ranks must report that same refusal and
+    # the test records it -- a reduce between two physical GPUs needs a larger machine.
+    import sys
+    helper = os.path.join(ROOT, "tests", "gpu_two_rank_rccl.py")
+    env = dict(os.environ, NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, helper, str(k), str(tmp_path)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True, env=env) for k in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            out, err = p.communicate(timeout=150)
+            outs.append((p.returncode, out.strip().splitlines()[-1] if out.strip() else "", err[-2000:]))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    print("two-rank RCCL on one device:", [o[:2] for o in outs])
+    assert all(rc == 0 for rc, _, _ in outs), outs
+    if all(line == "ok" for _, line, _ in outs):
+        sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+        with pa.Renderer(sc, pa.Settings(1, 50), 128, 72) as r:
+            r.render(10)
+            one = r.read_accum()
+        acc = np.load(tmp_path / "acc.npy")
+        assert np.all(acc[..., 3] == 1.0)
+        rel = np.abs(acc[..., :3] - one[..., :3]) / np.maximum(1.0, np.abs(one[..., :3]))
+        assert rel.max() <= 2e-6
+    else:
+        assert all(line.startswith("init_error 5 ") for _, line, _ in outs), outs     # ncclInvalidUsage on both ranks
