@@ -58,6 +58,8 @@ pub struct mi355pt_stats {
     pub exchange: [u64; 4],
     pub list_tiles: u32,
     pub list_candidates: u32,
+    pub sky_tiles: u32,
+    pub reserved: u32,
 }
 
 extern "C" {

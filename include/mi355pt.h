@@ -94,6 +94,9 @@ typedef struct mi355pt_stats {
     uint32_t list_tiles;      /* 8x8 pixel tiles whose camera rays tested a per-tile candidate list instead of walking
                                  the tree in the last launch (0: every camera ray walked) */
     uint32_t list_candidates; /* spheres on those lists, all tiles together */
+    uint32_t sky_tiles;       /* tiles with an empty list (nothing but sky) that the last launch accumulated pixel by pixel
+                                 in registers, bypassing the path kernel's queue and the per-frame result buffer */
+    uint32_t reserved;        /* keeps the struct a multiple of 8 bytes; always 0 */
 } mi355pt_stats;
 
 /* ---- context: Renderer::new / drop (mod.rs:106-146) ---------------------------------------- */

@@ -486,6 +486,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
         out->exchange_on = c->stats.exchange_on ? 1u : 0u;
         for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
         out->list_tiles = c->stats.list_tiles, out->list_candidates = c->stats.list_candidates;
+        out->sky_tiles = c->stats.sky_tiles;
         return MI355PT_OK;
     });
 }

@@ -275,7 +275,8 @@ __global__ void pt_tile_lists_kernel(const char* scene, SceneLayout L, Camera64 
     typedef uint32_t w4 __attribute__((ext_vector_type(4)));
     w4* out = reinterpret_cast<w4*>(lists + (size_t)t * TILE_LIST_WORDS);
     for (uint32_t k = 0; k < TILE_LIST_WORDS / 4u; k++) out[k] = w4{rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]};
-    if (rec[0] != TILE_LIST_WALK) atomicAdd(count, 1u), atomicAdd(count + 1, rec[0]);  // statistics only
+    if (rec[0] != TILE_LIST_WALK) atomicAdd(count, 1u), atomicAdd(count + 1, rec[0]);  // statistics
+    if (rec[0] == 0u) atomicAdd(count + 2, 1u);  // tiles that show nothing but sky (pt_sky_tiles_kernel)
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -1044,7 +1045,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
 // (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
 // measured 6x slower at 3840x2160.)
 __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
-                                  uint32_t tiles, uint32_t n_frames, const uint32_t* tile_perm,
+                                  uint32_t tiles, uint32_t active_tiles, uint32_t n_frames, const uint32_t* tile_perm,
                                   unsigned long long* ray_total, float* tile_cost, uint32_t compact,
                                   const unsigned long long* gave_up, unsigned long long* launches_added) {
     // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
@@ -1055,7 +1056,7 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
     const uint32_t rank = gid >> 6, slot = gid & 63u;
     unsigned long long rays = 0;
     uint32_t tile = 0;
-    if (rank < tiles) {
+    if (rank < active_tiles) {  // ranks beyond belong to pt_sky_tiles_kernel; `tiles` is the stride of the layout
         tile = tile_perm ? tile_perm[rank] : rank;
         const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
         if (px < width && py < height) {
@@ -1104,8 +1105,41 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
         // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
         // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
         if (rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
-        if (tile_cost && rank < tiles) tile_cost[tile] = (float)rays;
+        if (tile_cost && rank < active_tiles) tile_cost[tile] = (float)rays;
     }
+}
+
+// The tiles at ranks [first_rank, tiles) of the order show nothing but sky (their candidate lists are empty): every
+// path there is one camera ray and the sky colour.  One lane per pixel runs the frames of the launch in order and
+// adds them to the texel as it goes -- no result buffer, no queue, every lane busy.  Same arithmetic as the path
+// kernels followed by the accumulation kernel (sky_pixel_frame), so the texel's bits are the same.
+__global__ void __launch_bounds__(256) pt_sky_tiles_kernel(f4* accum, Camera64 cam64, uint32_t width, uint32_t height, uint32_t tiles_x,
+                                                          uint32_t first_rank, uint32_t tiles, uint32_t n_frames,
+                                                          const uint32_t* tile_perm, const uint32_t* seeds,
+                                                          const uint32_t* pixel_hash, unsigned long long* ray_total,
+                                                          const unsigned long long* gave_up) {
+    if (*gave_up) return;  // as pt_resolve_kernel: nothing of a launch whose path kernel gave up is added
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t rank = first_rank + (gid >> 6), slot = gid & 63u;
+    unsigned long long rays = 0;
+    if (rank < tiles) {
+        const uint32_t tile = tile_perm[rank];
+        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
+        if (px < width && py < height) {
+            const CameraRegs cam = load_camera(cam64);
+            const float fw = (float)width, fh = (float)height;
+            const uint32_t i = py * width + px, hash = pixel_hash[i];
+            f4 a = accum[i];
+            for (uint32_t f = 0; f < n_frames; f++) {
+                const V3 c = sky_pixel_frame(cam, px, py, fw, fh, seeds[f], hash);
+                a.x += c.x, a.y += c.y, a.z += c.z, a.w += 0.0f;
+            }
+            accum[i] = a;
+            rays = n_frames;  // one closest-hit query per path
+        }
+    }
+    rays = wave_sum(rays);
+    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
 }
 
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
@@ -1113,27 +1147,32 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
 constexpr int ORDER_BLK = 1024;
 // rank_chunk[r]: units a chunk starting in the r-th tile of that order should hold so that it costs about
 // `chunk_rays` rays (the cost of one unit of a tile = its measured rays / frames_measured).
+// With `lists` (the camera rays' candidate lists) the tiles whose list is empty -- sky and nothing else -- come
+// last, whatever they cost: launches that leave them to pt_sky_tiles_kernel end their queue before them.
 __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm,
                                                                  uint16_t* rank_chunk, float frames_measured,
-                                                                 float chunk_rays, uint32_t chunk_max) {
-    __shared__ uint32_t hist[256];
+                                                                 float chunk_rays, uint32_t chunk_max, const uint32_t* lists) {
+    __shared__ uint32_t hist[257];
     __shared__ float red[ORDER_BLK];
     float mx = 0.0f;
     for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) mx = fmaxf(mx, tile_cost[t]);
     red[threadIdx.x] = mx;
-    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    if (threadIdx.x < 257) hist[threadIdx.x] = 0u;
     __syncthreads();
     for (int o = ORDER_BLK / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
         __syncthreads();
     }
     const float scale = 255.0f / fmaxf(red[0], 1.0f);
-    auto bucket = [&](float c) { return 255u - min(255u, (uint32_t)(c * scale)); };  // 0 = most expensive
-    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) atomicAdd(&hist[bucket(tile_cost[t])], 1u);
+    auto bucket = [&](uint32_t t) {  // 0 = most expensive, 256 = sky only
+        if (lists && lists[(size_t)t * TILE_LIST_WORDS] == 0u) return 256u;
+        return 255u - min(255u, (uint32_t)(tile_cost[t] * scale));
+    };
+    for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) atomicAdd(&hist[bucket(t)], 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive prefix over 256 buckets
+    if (threadIdx.x == 0) {  // exclusive prefix over the buckets
         uint32_t run = 0;
-        for (int b = 0; b < 256; b++) {
+        for (int b = 0; b < 257; b++) {
             const uint32_t n = hist[b];
             hist[b] = run;
             run += n;
@@ -1142,7 +1181,7 @@ __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* t
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < tiles; t += ORDER_BLK) {
         const float c = tile_cost[t];
-        const uint32_t r = atomicAdd(&hist[bucket(c)], 1u);
+        const uint32_t r = atomicAdd(&hist[bucket(t)], 1u);
         perm[r] = t;
         const float unit_rays = fmaxf(c / frames_measured, 1.0f);
         rank_chunk[r] = (uint16_t)max(1u, min(chunk_max, (uint32_t)(chunk_rays / unit_rays)));
@@ -1178,6 +1217,7 @@ static void read_switches(Switches& s) {
         const char* nodes = getenv("MI355PT_NODES");
         s.ordered_global = !(nodes && strcmp(nodes, "plain") == 0);
     }
+    s.sky_tiles = env_long("MI355PT_SKY_TILES", 1) != 0;
     s.tile_lists = env_long("MI355PT_TILE_LISTS", 1) != 0;
     s.tile_list_max = (uint32_t)std::min<long>(TILE_LIST_CAP, std::max(0l, env_long("MI355PT_TILE_LIST_MAX", TILE_LIST_CAP)));
     if (const char* senv = getenv("MI355PT_XCHG_SCHED")) {
@@ -1556,11 +1596,8 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
         for (uint32_t k = 0; k < RAY_SLOTS; k++) stats.rays += slots[(size_t)k * RAY_SLOT_STRIDE];
     }
     stats.list_tiles = stats.list_candidates = 0;
-    if (d->lists_in_use) {
-        uint32_t lc[2];
-        PT_HIP(hipMemcpy(lc, d->list_count, sizeof lc, hipMemcpyDeviceToHost));
-        stats.list_tiles = lc[0], stats.list_candidates = lc[1];
-    }
+    if (d->lists_in_use) stats.list_tiles = d->list_counts[0], stats.list_candidates = d->list_counts[1];
+    stats.sky_tiles = d->sky_tiles_last;
     // The accumulation kernel counts the launches it has added (counters[9]); it skips a launch whose path kernel
     // gave up and every later one that was already queued, so the accumulator holds exactly the first `added` of
     // the queued launches, and only those are credited.
@@ -1813,12 +1850,16 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     if (sw.tile_lists && !lockstep && !d->layout.reference_walk && d->tile_lists) {
         d->lists_in_use = true;
         if (!d->lists_valid || memcmp(&cam, &d->lists_cam, sizeof cam) != 0) {
-            PT_HIP(hipMemsetAsync(d->list_count, 0, 8, d->stream));
+            PT_HIP(hipMemsetAsync(d->list_count, 0, 16, d->stream));
             hipLaunchKernelGGL(pt_tile_lists_kernel, dim3((tiles + 63u) / 64u), dim3(64), 0, d->stream, d->scene, d->layout, cam,
                                d->width, d->height, tiles_x, tiles, sw.tile_list_max, d->tile_lists, d->list_count);
             PT_HIP(hipGetLastError());
+            // the counts decide how later launches are split, so they are read back now: once per camera
+            PT_HIP(hipStreamSynchronize(d->stream));
+            PT_HIP(hipMemcpy(d->list_counts, d->list_count, sizeof d->list_counts, hipMemcpyDeviceToHost));
             d->lists_valid = true;
             d->lists_cam = cam;
+            d->perm_sky_last = false;  // an order made before these lists does not know their sky tiles
         }
         P.tile_lists = d->tile_lists;
     }
@@ -1877,6 +1918,16 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         // launches write and re-read 12 bytes per path.
         const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 63u);
         P.compact = measure ? 0u : 1u;
+        // Tiles that show nothing but sky (empty candidate lists; last in an order made with the lists) are left to
+        // pt_sky_tiles_kernel on launches of the plain kind: one sample per path, no counting, no cost measurement.
+        uint32_t sky_tiles = 0;
+        if (sw.sky_tiles && use_perm && d->perm_sky_last && d->lists_in_use && !measure && !cfg.count && cfg.samples == 1 &&
+            d->list_counts[2] < tiles)
+            sky_tiles = d->list_counts[2];
+        const uint32_t active_tiles = tiles - sky_tiles;
+        P.total_units = nb * active_tiles;
+        P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
+        d->sky_tiles_last = sky_tiles;
         P.ray_slots = d->ray_slots;
         PT_HIP(hipMemsetAsync(P.work_counter, 0, 4, d->stream));
         if (!timed_launch(false, [&]() {
@@ -1887,17 +1938,25 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
             return false;
         // accumulate in frame order (same stream: launches of one context never overlap)
         if (!timed_launch(true, [&]() {
-                hipLaunchKernelGGL(pt_resolve_kernel, dim3((tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
-                                   P.frame_out, d->width, d->height, tiles_x, tiles, nb, P.tile_perm, d->ray_slots,
+                hipLaunchKernelGGL(pt_resolve_kernel, dim3((active_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
+                                   P.frame_out, d->width, d->height, tiles_x, tiles, active_tiles, nb, P.tile_perm, d->ray_slots,
                                    measure ? d->tile_cost : nullptr, P.compact, d->counters + 10, d->counters + 9);
                 PT_HIP(hipGetLastError());
+                if (sky_tiles) {
+                    hipLaunchKernelGGL(pt_sky_tiles_kernel, dim3((sky_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum, cam,
+                                       d->width, d->height, tiles_x, active_tiles, tiles, nb, d->tile_perm, P.seeds, d->pixel_hash,
+                                       d->ray_slots, d->counters + 10);
+                    PT_HIP(hipGetLastError());
+                }
                 return true;
             }))
             return false;
         if (measure) {
             hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(ORDER_BLK), 0, d->stream, d->tile_cost, tiles,
-                               d->tile_perm, d->rank_chunk, (float)nb, chunk_rays, P.chunk_max);
+                               d->tile_perm, d->rank_chunk, (float)nb, chunk_rays, P.chunk_max,
+                               d->lists_in_use ? d->tile_lists : nullptr);
             PT_HIP(hipGetLastError());
+            d->perm_sky_last = d->lists_in_use;
             d->perm_valid = true;
             d->perm_cam = cam;
             d->perm_depth = cfg.depth, d->perm_samples = cfg.samples;

@@ -850,6 +850,16 @@ PT_FN void tile_list_build(const Mem& mem, const SceneLayout& L, const Camera64&
     }
     rec[0] = overflow ? TILE_LIST_WALK : count;
 }
+// One frame of a pixel whose tile has an empty candidate list: the camera ray cannot reach a sphere, so the path is
+// jitter, camera ray, sky (compute.wgsl:405-415 with trace_path returning colour * miss(dir.y), colour = 1).  The
+// value is what the path kernels hand to the accumulation: final_colour = 0 + colour * sky.
+PT_FN V3 sky_pixel_frame(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, float fh, uint32_t frame_seed, uint32_t hash) {
+    uint32_t rng = pixel_seed(frame_seed, hash);
+    const V3 d = camera_dir(cam, px, py, fw, fh, rng);
+    const V3 radiance = mk(1.0f, 1.0f, 1.0f) * sky(d.y);
+    return mk(0.0f, 0.0f, 0.0f) + radiance;
+}
+
 // Closest hit of a camera ray over its tile's candidate list: what the walk finds, without the walk.
 template <class Mem, bool COUNT>
 PT_FN void walk_tile_list(const Mem& mem, const SceneLayout& L, Walk& w, V3 o, V3 d, const uint32_t* rec, Counters& cnt) {

@@ -668,3 +668,33 @@ def test_camera_ray_candidate_lists_are_bit_identical(pa, orc, monkeypatch):
         want, _ = orc.render(oother, oother.camera(96, 64), 96, 64, seeds[:2], samples=3, depth=7, threads=8)
         assert bits_equal(want, r.read_accum())
         assert r.stats()["list_tiles"] == 12 * 8   # scene3: ten spheres, every tile has a list
+
+
+def test_sky_only_tiles_accumulated_per_pixel_are_bit_identical(pa, orc, monkeypatch):
+    # Tiles whose candidate list is empty show nothing but sky.  Once the tile order has been measured (a launch of
+    # at least 8 frames) they sit at the end of the order, and launches of the plain kind leave them to
+    # pt_sky_tiles_kernel: one lane per pixel adds the frames in order, no result buffer.  Same bits as the oracle,
+    # same ray count, whether the split is on or off, over several launches and with queued calls.
+    for name, (W, H) in (("scene1.ron", (320, 180)), ("scene2.ron", (203, 117))):
+        path = os.path.join(FIXTURES, name)
+        sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+        seeds = np.arange(100, 100 + 27, dtype=np.uint32) * np.uint32(2246822519)
+        ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("MI355PT_SKY_TILES", "0")
+            with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+                r.render(seeds=seeds[:9])                   # measures the tile order: every tile through the path kernel
+                assert r.stats()["sky_tiles"] == 0
+                r.render(seeds=seeds[9:12])                 # ordered: sky tiles split off
+                split = r.stats()["sky_tiles"]
+                assert (split == 0) if off else (0 < split < r.stats()["list_tiles"])
+                r.render(seeds=seeds[12:20], wait=False)
+                r.render(seeds=seeds[20:], wait=False)
+                s = r.stats()
+                assert bits_equal(ref, r.read_accum()) and s["rays"] == st["rays"] and s["paths"] == st["paths"], (name, off)
+                r.reload_settings(pa.Settings(2, 50))       # two samples per path: the split steps aside
+                r.render(seeds=seeds[:2])
+                assert r.stats()["sky_tiles"] == 0
+            if off:
+                monkeypatch.delenv("MI355PT_SKY_TILES")
