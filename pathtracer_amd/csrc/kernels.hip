@@ -976,21 +976,25 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                 ps.o = cam.pos;
                 ps.colour = mk(1.0f, 1.0f, 1.0f);
                 ps.bounce = 0;
-                walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
                 if constexpr (FAST) lane_rays++; else rays++;
+                bool walks = true;
                 if constexpr (SCENE != SCENE_REFERENCE) {
                     // Camera rays test the candidates of their tile instead of walking the tree (tile_list_build);
-                    // the lanes of a restart step share a tile or two, so the loop below runs nearly uniform.
+                    // the lanes of a restart step share a tile or two, so the loop below runs nearly uniform.  Such
+                    // a ray needs none of the walk's per-ray set-up (reciprocal direction, signs, stack).
                     if (Q->tile_lists) {
                         const uint32_t tile_id = (pxy_now >> 19) * Q->tiles_x + ((pxy_now & 0xffffu) >> 3);
                         const uint32_t* rec = Q->tile_lists + (size_t)tile_id * TILE_LIST_WORDS;
                         const uint32_t n = rec[0];
                         if (n != TILE_LIST_WALK) {
+                            walks = false;
+                            w.best_t = INFINITY, w.best_code = -1, w.sp = 0;
                             for (uint32_t k = 0; k < n; k++) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, rec[1u + k], cnt);
                             w.cur = WALK_FINISHED;
                         }
                     }
                 }
+                if (walks) walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
             }
         }
         if (!ran) {
