@@ -56,9 +56,10 @@ CONFIGS = {
 }
 
 
-def measure_config(pa, src, W, H, F, device=0, bvh_mode=None, count_frames=4):
-    """One configuration on one GPU: F frames in one call after a warm-up that also measures the tile order;
-    kernel time from the library's HIP events; visit counts from the instrumented kernels on a few frames."""
+def measure_config(pa, src, W, H, F, device=0, bvh_mode=None, count_frames=4, repeats=3):
+    """One configuration on one GPU: F frames in one call, `repeats` times after a warm-up that also measures the
+    tile order, the median call reported (the first call after a pause runs at lower clocks); kernel time from the
+    library's HIP events; visit counts from the instrumented kernels on a few frames."""
     from pathtracer_amd import synth
     t0 = time.perf_counter()
     sc = pa.load_ron_scene(os.path.join(ROOT, "fixtures", src)) if isinstance(src, str) else synth.plane_scene(src)
@@ -68,11 +69,16 @@ def measure_config(pa, src, W, H, F, device=0, bvh_mode=None, count_frames=4):
     with pa.Renderer(sc, pa.Settings(1, 50), W, H, device=device, **kw) as r:
         t_create = time.perf_counter() - t0
         r.render(min(F, 16))
-        r.clear()
-        t0 = time.perf_counter()
-        r.render(F)
-        wall = time.perf_counter() - t0
-        s = r.stats()
+        runs = []
+        for _ in range(max(1, repeats)):
+            r.clear()
+            t0 = time.perf_counter()
+            r.render(F)
+            wall = time.perf_counter() - t0
+            s = r.stats()
+            runs.append((s["render_ms"], wall, s))
+        runs.sort(key=lambda x: x[0])
+        _, wall, s = runs[len(runs) // 2]
     with pa.Renderer(sc, pa.Settings(1, 50), W, H, device=device, flags=pa.FLAG_COUNT, **kw) as rc:
         rc.render(min(F, count_frames))
         c = rc.stats()
@@ -89,7 +95,8 @@ def measure_config(pa, src, W, H, F, device=0, bvh_mode=None, count_frames=4):
             "scene_fetch_GBps": by * s["rays"] / k_ms / 1e6,
             "scene_in_lds": bool(s["scene_in_lds"]), "scene_MB": s["scene_bytes"] / 1e6,
             "bvh_nodes": s["bvh_nodes"], "bvh_depth": s["bvh_depth"],
-            "camera_ray_list_tiles": s["list_tiles"], "tiles": ((W + 7) // 8) * ((H + 7) // 8),
+            "camera_ray_list_tiles": s["list_tiles"], "sky_tiles": s["sky_tiles"], "tiles": ((W + 7) // 8) * ((H + 7) // 8),
+            "repeats": len(runs), "kernel_ms_all": [x[0] for x in runs],
             "scene_s": t_scene, "create_s": t_create}
 
 

@@ -985,11 +985,17 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     if (Q->tile_lists) {
                         const uint32_t tile_id = (pxy_now >> 19) * Q->tiles_x + ((pxy_now & 0xffffu) >> 3);
                         const uint32_t* rec = Q->tile_lists + (size_t)tile_id * TILE_LIST_WORDS;
-                        const uint32_t n = rec[0];
+                        // count and the first three candidates in one fetch: all that nine tiles in ten hold
+                        typedef uint32_t w4 __attribute__((ext_vector_type(4)));
+                        const w4 head = *reinterpret_cast<const w4*>(rec);
+                        const uint32_t n = head.x;
                         if (n != TILE_LIST_WALK) {
                             walks = false;
                             w.best_t = INFINITY, w.best_code = -1, w.sp = 0;
-                            for (uint32_t k = 0; k < n; k++) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, rec[1u + k], cnt);
+                            if (n > 0u) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, head.y, cnt);
+                            if (n > 1u) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, head.z, cnt);
+                            if (n > 2u) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, head.w, cnt);
+                            for (uint32_t k = 3; k < n; k++) walk_test_sphere<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, rec[1u + k], cnt);
                             w.cur = WALK_FINISHED;
                         }
                     }
@@ -1114,36 +1120,45 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
 }
 
 // The tiles at ranks [first_rank, tiles) of the order show nothing but sky (their candidate lists are empty): every
-// path there is one camera ray and the sky colour.  One lane per pixel runs the frames of the launch in order and
-// adds them to the texel as it goes -- no result buffer, no queue, every lane busy.  Same arithmetic as the path
-// kernels followed by the accumulation kernel (sky_pixel_frame), so the texel's bits are the same.
-__global__ void __launch_bounds__(256) pt_sky_tiles_kernel(f4* accum, Camera64 cam64, uint32_t width, uint32_t height, uint32_t tiles_x,
-                                                          uint32_t first_rank, uint32_t tiles, uint32_t n_frames,
-                                                          const uint32_t* tile_perm, const uint32_t* seeds,
-                                                          const uint32_t* pixel_hash, unsigned long long* ray_total,
-                                                          const unsigned long long* gave_up) {
+// path there is one camera ray and the sky colour.  No queue and no result buffer: a workgroup owns a tile, its
+// four waves work out the colours of four consecutive frames of the tile's 64 pixels side by side (the colours
+// do not depend on one another, only the sums do), and the first wave adds them to its running sums in frame
+// order.  Same arithmetic as the path kernels followed by the accumulation kernel (sky_pixel_frame), so the
+// texel's bits are the same.
+constexpr uint32_t SKY_FRAMES = 4;  // frames in flight per tile = waves per workgroup
+__global__ void __launch_bounds__(64 * SKY_FRAMES) pt_sky_tiles_kernel(f4* accum, Camera64 cam64, uint32_t width, uint32_t height,
+                                                                      uint32_t tiles_x, uint32_t first_rank, uint32_t n_frames,
+                                                                      const uint32_t* tile_perm, const uint32_t* seeds,
+                                                                      const uint32_t* pixel_hash, unsigned long long* ray_total,
+                                                                      const unsigned long long* gave_up) {
     if (*gave_up) return;  // as pt_resolve_kernel: nothing of a launch whose path kernel gave up is added
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t rank = first_rank + (gid >> 6), slot = gid & 63u;
-    unsigned long long rays = 0;
-    if (rank < tiles) {
-        const uint32_t tile = tile_perm[rank];
-        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
-        if (px < width && py < height) {
-            const CameraRegs cam = load_camera(cam64);
-            const float fw = (float)width, fh = (float)height;
-            const uint32_t i = py * width + px, hash = pixel_hash[i];
-            f4 a = accum[i];
-            for (uint32_t f = 0; f < n_frames; f++) {
-                const V3 c = sky_pixel_frame(cam, px, py, fw, fh, seeds[f], hash);
-                a.x += c.x, a.y += c.y, a.z += c.z, a.w += 0.0f;
-            }
-            accum[i] = a;
-            rays = n_frames;  // one closest-hit query per path
+    __shared__ float colour[SKY_FRAMES][3][64];
+    const uint32_t slot = threadIdx.x & 63u, sub = threadIdx.x >> 6;
+    const uint32_t tile = tile_perm[first_rank + blockIdx.x];
+    const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
+    const bool inside = px < width && py < height;  // the barriers below are reached by every lane
+    const CameraRegs cam = load_camera(cam64);
+    const float fw = (float)width, fh = (float)height;
+    const uint32_t i = inside ? py * width + px : 0u, hash = pixel_hash[i];
+    f4 a = accum[i];
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += SKY_FRAMES) {
+        const uint32_t f = f0 + sub;
+        if (f < n_frames) {
+            const V3 c = sky_pixel_frame(cam, px, py, fw, fh, seeds[f], hash);
+            colour[sub][0][slot] = c.x, colour[sub][1][slot] = c.y, colour[sub][2][slot] = c.z;
         }
+        __syncthreads();
+        if (sub == 0) {
+            const uint32_t n = min(SKY_FRAMES, n_frames - f0);
+            for (uint32_t k = 0; k < n; k++) a.x += colour[k][0][slot], a.y += colour[k][1][slot], a.z += colour[k][2][slot], a.w += 0.0f;
+        }
+        __syncthreads();
     }
-    rays = wave_sum(rays);
-    if ((threadIdx.x & 63u) == 0 && rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+    if (sub == 0) {
+        if (inside) accum[i] = a;
+        const unsigned long long rays = wave_sum(inside ? (unsigned long long)n_frames : 0ull);  // one closest-hit query per path
+        if (slot == 0 && rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+    }
 }
 
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
@@ -1947,8 +1962,8 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
                                    measure ? d->tile_cost : nullptr, P.compact, d->counters + 10, d->counters + 9);
                 PT_HIP(hipGetLastError());
                 if (sky_tiles) {
-                    hipLaunchKernelGGL(pt_sky_tiles_kernel, dim3((sky_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum, cam,
-                                       d->width, d->height, tiles_x, active_tiles, tiles, nb, d->tile_perm, P.seeds, d->pixel_hash,
+                    hipLaunchKernelGGL(pt_sky_tiles_kernel, dim3(sky_tiles), dim3(64 * SKY_FRAMES), 0, d->stream, d->accum, cam,
+                                       d->width, d->height, tiles_x, active_tiles, nb, d->tile_perm, P.seeds, d->pixel_hash,
                                        d->ray_slots, d->counters + 10);
                     PT_HIP(hipGetLastError());
                 }
