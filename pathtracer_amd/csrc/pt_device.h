@@ -726,6 +726,8 @@ constexpr uint32_t TILE_LIST_WALK = 0xffffffffu;            // count word: camer
 struct TileCone {
     double n[4][3];   // unit normals of the four side planes through the camera position, pointing inwards
     double org[3];    // camera position
+    double axis[3];   // unit direction through the middle of the tile
+    double cos_a, sin_a;  // of the largest angle between the axis and a corner direction, widened by ang_err
     double ang_err;   // bound on the angle between a computed (binary32) direction and the exact one
     bool valid;
 };
@@ -771,14 +773,45 @@ PT_FN void tile_cone(const Camera64& cam, uint32_t tx, uint32_t ty, uint32_t w, 
     // center + horizontal * nx + vertical * ny - pos in binary32: four roundings of terms of size `mag`
     c.ang_err = ok ? 4.0 * 1.2e-7 * mag / min_len + 1e-6 : 0.0;
     c.valid = ok && c.ang_err < 1e-3;
+    // The circular cone around the tile: every direction of the tile lies within its angle of the axis (the
+    // directions are convex combinations of the corner directions, and the angle to a fixed axis is largest at
+    // a corner).  The four planes alone do not bound the cone behind the camera, where a huge ball -- the ground
+    // sphere of every shipped scene -- crosses all of them although no ray of the tile can reach it.
+    if (c.valid) {
+        const double lc = sqrt(dc[0] * dc[0] + dc[1] * dc[1] + dc[2] * dc[2]);
+        double cos_min = 1.0;
+        for (int a = 0; a < 3; a++) c.axis[a] = dc[a] / lc;
+        for (int k = 0; k < 4; k++) {
+            const double l = sqrt(d[k][0] * d[k][0] + d[k][1] * d[k][1] + d[k][2] * d[k][2]);
+            cos_min = fmin(cos_min, (d[k][0] * c.axis[0] + d[k][1] * c.axis[1] + d[k][2] * c.axis[2]) / l);
+        }
+        // widen by the direction error and a little more: cos(alpha + e) >= cos(alpha) - e
+        c.cos_a = fmax(-1.0, cos_min - c.ang_err - 1e-9);
+        c.sin_a = sqrt(fmax(0.0, 1.0 - c.cos_a * c.cos_a));
+        c.valid = c.cos_a > 0.0;  // narrower than a right angle (any sensible tile is far narrower)
+    }
 }
 // May a camera ray of the tile reach the ball of radius `rad` around (cx, cy, cz)?  (Never false for one that can.)
 PT_FN bool tile_cone_meets_ball(const TileCone& c, double cx, double cy, double cz, double rad) {
     const double ox = cx - c.org[0], oy = cy - c.org[1], oz = cz - c.org[2];
     const double dist = sqrt(ox * ox + oy * oy + oz * oz);
-    const double reach = rad * (1.0 + 1e-5) + 0.01 + c.ang_err * (dist + rad);
+    // The ball a ray must miss for the sphere test to be sure to miss: the sphere, the reference's 0.01 padding, and
+    // what the test's own rounding can add -- its discriminant hb^2 - (|oc|^2 - r^2) carries a few units in the last
+    // place of |oc|^2, i.e. about 4e-7 dist^2 in the squared distance of the ray from the centre, which is
+    // 4e-7 dist^2 / (2 r) in that distance (twice that here).  The direction error widens the cone, not the ball: as
+    // an angle it is a length ang_err * dist at the centre's distance for the planes, and part of cos_a for the cone.
+    const double reach = rad + 0.01 + 4e-7 * dist * dist / fmax(rad, 1e-9);
+    const double reach_planes = reach + c.ang_err * dist;
     for (int k = 0; k < 4; k++)
-        if (c.n[k][0] * ox + c.n[k][1] * oy + c.n[k][2] * oz < -reach) return false;
+        if (c.n[k][0] * ox + c.n[k][1] * oy + c.n[k][2] * oz < -reach_planes) return false;
+    // against the circular cone: the ball (angular radius beta as seen from the camera, centre at angle phi from
+    // the axis) is out of reach when phi > alpha + beta, i.e. cos(phi) < cos(alpha + beta); both angles are below
+    // a right angle, so the comparison of cosines is the comparison of angles
+    if (dist > reach) {
+        const double sin_b = reach / dist, cos_b = sqrt(fmax(0.0, 1.0 - sin_b * sin_b));
+        const double cos_phi = (ox * c.axis[0] + oy * c.axis[1] + oz * c.axis[2]) / dist;
+        if (cos_phi < c.cos_a * cos_b - c.sin_a * sin_b - 1e-9) return false;
+    }
     return true;
 }
 // The same for an axis-aligned box (a node's child box, which already holds its spheres' padding).
