@@ -50,7 +50,7 @@ struct Switches {
     bool ordered_global = true;                 // MI355PT_NODES=plain: trees in global memory are walked as Node64 records
     bool exchange_global = true;                // MI355PT_XCHG_GLOBAL=0: no exchange variant for trees in global memory
     bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
-    uint32_t xthr[6] = {12, 8, 24, 24, 12, 28}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
+    uint32_t xthr[6] = {10, 6, 24, 24, 16, 32}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
     bool sky_tiles = true;                      // MI355PT_SKY_TILES=0: tiles that show only sky go through the path kernel like the rest
     bool tile_lists = true;                     // MI355PT_TILE_LISTS=0: camera rays walk the tree like every other ray
     uint32_t tile_list_max = TILE_LIST_CAP;     // MI355PT_TILE_LIST_MAX: tiles with more candidates keep the walk
