@@ -59,7 +59,7 @@ pub struct mi355pt_stats {
     pub list_tiles: u32,
     pub list_candidates: u32,
     pub sky_tiles: u32,
-    pub reserved: u32,
+    pub short_div: u32,
 }
 
 extern "C" {

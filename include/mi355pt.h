@@ -96,7 +96,9 @@ typedef struct mi355pt_stats {
     uint32_t list_candidates; /* spheres on those lists, all tiles together */
     uint32_t sky_tiles;       /* tiles with an empty list (nothing but sky) that the last launch accumulated pixel by pixel
                                  in registers, bypassing the path kernel's queue and the per-frame result buffer */
-    uint32_t reserved;        /* keeps the struct a multiple of 8 bytes; always 0 */
+    uint32_t short_div;       /* 1 when the camera rays' divisions by width and height run as a three-instruction sequence that the
+                                 device verified, for this image size, to give the correctly rounded quotient for every
+                                 possible pixel coordinate */
 } mi355pt_stats;
 
 /* ---- context: Renderer::new / drop (mod.rs:106-146) ---------------------------------------- */

@@ -35,7 +35,7 @@ class Stats(C.Structure):
                 ("bvh_depth", C.c_uint32), ("scene_bytes", C.c_uint32), ("scene_in_lds", C.c_uint32),
                 ("node_format", C.c_uint32), ("exchange_on", C.c_uint32), ("exchange", C.c_uint64 * 4),
                 ("list_tiles", C.c_uint32), ("list_candidates", C.c_uint32),
-                ("sky_tiles", C.c_uint32), ("reserved", C.c_uint32)]
+                ("sky_tiles", C.c_uint32), ("short_div", C.c_uint32)]
 
 
 # name -> (restype, argtypes); the single list the symbol-export test walks

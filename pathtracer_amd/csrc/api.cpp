@@ -487,6 +487,7 @@ int mi355pt_stats_get(mi355pt_ctx* c, mi355pt_stats* out) {
         for (int k = 0; k < 4; k++) out->exchange[k] = c->stats.exchange[k];
         out->list_tiles = c->stats.list_tiles, out->list_candidates = c->stats.list_candidates;
         out->sky_tiles = c->stats.sky_tiles;
+        out->short_div = c->stats.short_div ? 1u : 0u;
         return MI355PT_OK;
     });
 }

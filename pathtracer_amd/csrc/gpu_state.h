@@ -51,6 +51,7 @@ struct Switches {
     bool exchange_global = true;                // MI355PT_XCHG_GLOBAL=0: no exchange variant for trees in global memory
     bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
     uint32_t xthr[6] = {10, 6, 24, 24, 16, 32}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
+    bool short_div = true;                      // MI355PT_SHORT_DIV=0: pixel coordinates are always divided the general way
     bool sky_tiles = true;                      // MI355PT_SKY_TILES=0: tiles that show only sky go through the path kernel like the rest
     bool tile_lists = true;                     // MI355PT_TILE_LISTS=0: camera rays walk the tree like every other ray
     uint32_t tile_list_max = TILE_LIST_CAP;     // MI355PT_TILE_LIST_MAX: tiles with more candidates keep the walk
@@ -100,6 +101,8 @@ struct Device {
     uint32_t list_counts[4] = {0, 0, 0, 0};  // host copy of list_count: tiles with a list, entries, tiles with an empty list
     bool perm_sky_last = false;      // tile_perm was made with these lists: the tiles with an empty list are its last ranks
     uint32_t sky_tiles_last = 0;     // tiles the last launch left to pt_sky_tiles_kernel
+    float rcp_w = 0.0f, rcp_h = 0.0f;  // 1 / width, 1 / height
+    bool short_div = false;          // PixelDiv's short sequence verified for this width and height (resize)
     bool lists_valid = false;
     Camera64 lists_cam{};
     uint32_t* seeds = nullptr;  // ring: every enqueued call owns a contiguous range until finish()

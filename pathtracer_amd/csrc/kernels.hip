@@ -219,6 +219,8 @@ struct RenderParams {
     uint32_t pool_off;
     const char* onodes;  // SCENE_GLOBAL_ORDERED: the tree as direction-ordered records
     const uint32_t* tile_lists;  // pt_render_sched_kernel: per tile TILE_LIST_WORDS words, the candidates of its camera rays (null: none)
+    float rcp_w, rcp_h;          // 1 / width, 1 / height
+    uint32_t short_div;          // 1: the short division by width and height was verified for this image size (PixelDiv)
 };
 
 // Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
@@ -972,7 +974,9 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
             if (w.cur == LANE_NEXT) {
                 const CameraRegs cam = {mk(Q->cam.pos[0], Q->cam.pos[1], Q->cam.pos[2]), mk(Q->cam.horizontal[0], Q->cam.horizontal[1], Q->cam.horizontal[2]),
                                         mk(Q->cam.vertical[0], Q->cam.vertical[1], Q->cam.vertical[2]), mk(Q->cam.center[0], Q->cam.center[1], Q->cam.center[2])};
-                ps.d = camera_dir(cam, pxy_now & 0xffffu, pxy_now >> 16, (float)Q->width, (float)Q->height, ps.rng);
+                const bool short_div = Q->short_div != 0u;
+                ps.d = camera_dir(cam, pxy_now & 0xffffu, pxy_now >> 16, PixelDiv((float)Q->width, Q->rcp_w, short_div),
+                                  PixelDiv((float)Q->height, Q->rcp_h, short_div), ps.rng);
                 ps.o = cam.pos;
                 ps.colour = mk(1.0f, 1.0f, 1.0f);
                 ps.bounce = 0;
@@ -1130,7 +1134,8 @@ __global__ void __launch_bounds__(64 * SKY_FRAMES) pt_sky_tiles_kernel(f4* accum
                                                                       uint32_t tiles_x, uint32_t first_rank, uint32_t n_frames,
                                                                       const uint32_t* tile_perm, const uint32_t* seeds,
                                                                       const uint32_t* pixel_hash, unsigned long long* ray_total,
-                                                                      const unsigned long long* gave_up) {
+                                                                      const unsigned long long* gave_up, float rcp_w, float rcp_h,
+                                                                      uint32_t short_div) {
     if (*gave_up) return;  // as pt_resolve_kernel: nothing of a launch whose path kernel gave up is added
     __shared__ float colour[SKY_FRAMES][3][64];
     const uint32_t slot = threadIdx.x & 63u, sub = threadIdx.x >> 6;
@@ -1138,7 +1143,7 @@ __global__ void __launch_bounds__(64 * SKY_FRAMES) pt_sky_tiles_kernel(f4* accum
     const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
     const bool inside = px < width && py < height;  // the barriers below are reached by every lane
     const CameraRegs cam = load_camera(cam64);
-    const float fw = (float)width, fh = (float)height;
+    const PixelDiv fw((float)width, rcp_w, short_div != 0u), fh((float)height, rcp_h, short_div != 0u);
     const uint32_t i = inside ? py * width + px : 0u, hash = pixel_hash[i];
     f4 a = accum[i];
     for (uint32_t f0 = 0; f0 < n_frames; f0 += SKY_FRAMES) {
@@ -1207,6 +1212,19 @@ __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* t
     }
 }
 
+// Is PixelDiv's short division by `d` exact?  Compares it with the general division for every binary32 numerator
+// with bits in [lo, hi] and for zero; any difference sets *bad.  Run once per image size and divisor (resize).
+__global__ void pt_verify_div_kernel(float d, float rcp, uint32_t lo, uint32_t hi, uint32_t* bad) {
+    const PixelDiv div(d, rcp, true);
+    bool differs = false;
+    for (uint64_t b = (uint64_t)lo + blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; b <= hi; b += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = __uint_as_float((uint32_t)b);
+        differs |= __float_as_uint(div.short_quotient(x)) != __float_as_uint(x / d);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) differs |= __float_as_uint(div.short_quotient(0.0f)) != __float_as_uint(0.0f / d);
+    if (__ballot(differs) && (threadIdx.x & 63u) == 0) atomicOr(bad, 1u);
+}
+
 __global__ void pt_fill_kernel(f4* p, uint32_t n, f4 v) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1236,6 +1254,7 @@ static void read_switches(Switches& s) {
         const char* nodes = getenv("MI355PT_NODES");
         s.ordered_global = !(nodes && strcmp(nodes, "plain") == 0);
     }
+    s.short_div = env_long("MI355PT_SHORT_DIV", 1) != 0;
     s.sky_tiles = env_long("MI355PT_SKY_TILES", 1) != 0;
     s.tile_lists = env_long("MI355PT_TILE_LISTS", 1) != 0;
     s.tile_list_max = (uint32_t)std::min<long>(TILE_LIST_CAP, std::max(0l, env_long("MI355PT_TILE_LIST_MAX", TILE_LIST_CAP)));
@@ -1469,6 +1488,21 @@ bool resize(Device* d, uint32_t width, uint32_t height, std::string& err) {
     hipLaunchKernelGGL(pt_hash_kernel, dim3((n_pix + 255) / 256), dim3(256), 0, d->stream, d->pixel_hash, width,
                        height);
     PT_HIP(hipGetLastError());
+    // The short division of the camera rays' pixel coordinates (PixelDiv) is used only if it gives the general
+    // division's bits for every numerator there can be -- px + r with px < 65536 and r in [2^-32, 1] or r = 0 --
+    // which the device checks here, once per size, for both divisors (0.8 G quotients: under a millisecond).
+    d->rcp_w = 1.0f / (float)width, d->rcp_h = 1.0f / (float)height;
+    d->short_div = false;
+    if (d->sw.short_div) {
+        PT_HIP(hipMemsetAsync(d->list_count + 8, 0, 4, d->stream));
+        hipLaunchKernelGGL(pt_verify_div_kernel, dim3(4096), dim3(256), 0, d->stream, (float)width, d->rcp_w, 0x2F800000u, 0x47800000u, d->list_count + 8);
+        hipLaunchKernelGGL(pt_verify_div_kernel, dim3(4096), dim3(256), 0, d->stream, (float)height, d->rcp_h, 0x2F800000u, 0x47800000u, d->list_count + 8);
+        PT_HIP(hipGetLastError());
+        uint32_t bad = 1;
+        PT_HIP(hipStreamSynchronize(d->stream));
+        PT_HIP(hipMemcpy(&bad, d->list_count + 8, 4, hipMemcpyDeviceToHost));
+        d->short_div = bad == 0u;
+    }
     return clear(d, err);
 }
 
@@ -1617,6 +1651,7 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
     stats.list_tiles = stats.list_candidates = 0;
     if (d->lists_in_use) stats.list_tiles = d->list_counts[0], stats.list_candidates = d->list_counts[1];
     stats.sky_tiles = d->sky_tiles_last;
+    stats.short_div = d->short_div;
     // The accumulation kernel counts the launches it has added (counters[9]); it skips a launch whose path kernel
     // gave up and every later one that was already queued, so the accumulator holds exactly the first `added` of
     // the queued launches, and only those are credited.
@@ -1732,6 +1767,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     P.work_counter = fixed ? fixed->work_counter : d->work_counter;
     P.counters = d->counters;
     P.glass_always_draws = cfg.glass_always_draws ? 1 : 0;
+    P.rcp_w = d->rcp_w, P.rcp_h = d->rcp_h, P.short_div = d->short_div ? 1u : 0u;
     const bool lockstep = sw.lockstep;
     P.watchdog_ticks = sw.watchdog_ms * 100000ull;  // 100 MHz
     P.inv_tiles_x = 1.0f / (float)tiles_x;
@@ -1964,7 +2000,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
                 if (sky_tiles) {
                     hipLaunchKernelGGL(pt_sky_tiles_kernel, dim3(sky_tiles), dim3(64 * SKY_FRAMES), 0, d->stream, d->accum, cam,
                                        d->width, d->height, tiles_x, active_tiles, nb, d->tile_perm, P.seeds, d->pixel_hash,
-                                       d->ray_slots, d->counters + 10);
+                                       d->ray_slots, d->counters + 10, P.rcp_w, P.rcp_h, P.short_div);
                     PT_HIP(hipGetLastError());
                 }
                 return true;

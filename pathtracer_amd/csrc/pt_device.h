@@ -188,12 +188,28 @@ PT_FN CameraRegs load_camera(const Camera64& c) {
     r.center = mk(c.center[0], c.center[1], c.center[2]);
     return r;
 }
+// Division of a jittered pixel coordinate by the image width or height (compute.wgsl:407-409).  The quotient that
+// reaches a pixel is the correctly rounded one.  With `exact_short` it is formed as q = x * rcp, then one
+// correction q + fma(-q, d, x) * rcp -- three instructions instead of the eleven of the general expansion -- which
+// is only ever set after the device has compared the two for EVERY numerator a pixel coordinate can be (all
+// binary32 values in [2^-32, 65536] and zero; pt_verify_div_kernel), for this very divisor.
+struct PixelDiv {
+    float d, rcp;
+    bool exact_short;
+    PT_FN PixelDiv(float divisor) : d(divisor), rcp(0.0f), exact_short(false) {}
+    PT_FN PixelDiv(float divisor, float reciprocal, bool verified) : d(divisor), rcp(reciprocal), exact_short(verified) {}
+    PT_FN float short_quotient(float x) const {
+        const float q = x * rcp;
+        return PT_FMA(PT_FMA(-q, d, x), rcp, q);
+    }
+    PT_FN float of(float x) const { return exact_short ? short_quotient(x) : x / d; }
+};
 // Draws the two jitter numbers (x first) and returns the primary direction.
-PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, float fh, uint32_t& rng) {
+PT_FN V3 camera_dir(const CameraRegs& cam, uint32_t px, uint32_t py, PixelDiv fw, PixelDiv fh, uint32_t& rng) {
     float rx = randf(rng);
     float ry = randf(rng);
-    float ux = ((float)px + rx) / fw;
-    float uy = ((float)py + ry) / fh;
+    float ux = fw.of((float)px + rx);
+    float uy = fh.of((float)py + ry);
     float nx = PT_TWICE_MINUS_ONE(ux);
     float ny = -PT_TWICE_MINUS_ONE(uy);
     return normalize3(cam.center + cam.horizontal * nx + cam.vertical * ny - cam.pos);
@@ -886,7 +902,7 @@ PT_FN void tile_list_build(const Mem& mem, const SceneLayout& L, const Camera64&
 // One frame of a pixel whose tile has an empty candidate list: the camera ray cannot reach a sphere, so the path is
 // jitter, camera ray, sky (compute.wgsl:405-415 with trace_path returning colour * miss(dir.y), colour = 1).  The
 // value is what the path kernels hand to the accumulation: final_colour = 0 + colour * sky.
-PT_FN V3 sky_pixel_frame(const CameraRegs& cam, uint32_t px, uint32_t py, float fw, float fh, uint32_t frame_seed, uint32_t hash) {
+PT_FN V3 sky_pixel_frame(const CameraRegs& cam, uint32_t px, uint32_t py, PixelDiv fw, PixelDiv fh, uint32_t frame_seed, uint32_t hash) {
     uint32_t rng = pixel_seed(frame_seed, hash);
     const V3 d = camera_dir(cam, px, py, fw, fh, rng);
     const V3 radiance = mk(1.0f, 1.0f, 1.0f) * sky(d.y);

@@ -698,3 +698,29 @@ def test_sky_only_tiles_accumulated_per_pixel_are_bit_identical(pa, orc, monkeyp
                 assert r.stats()["sky_tiles"] == 0
             if off:
                 monkeypatch.delenv("MI355PT_SKY_TILES")
+
+
+def test_short_pixel_division_is_verified_and_changes_no_bit(pa, orc, monkeypatch):
+    # The camera rays' divisions by width and height run as x * (1/d) plus one correction step when the device has
+    # found that sequence equal to the correctly rounded quotient for every possible pixel coordinate (checked per
+    # image size at resize; stats report whether it is in use).  With it, without it and in the oracle: same bits.
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene3.ron"))
+    osc = oracle_scene(orc, sc)
+    used = {}
+    for W, H in ((1920, 1080), (1280, 720), (400, 225), (37, 23), (1, 1), (129, 65), (1000, 3)):
+        seeds = SEEDS[:2] if W * H > 500_000 else SEEDS
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+            r.render(seeds=seeds)
+            a, used[(W, H)] = r.read_accum(), r.stats()["short_div"]
+        monkeypatch.setenv("MI355PT_SHORT_DIV", "0")
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+            r.render(seeds=seeds)
+            b = r.read_accum()
+            assert r.stats()["short_div"] == 0
+        monkeypatch.delenv("MI355PT_SHORT_DIV")
+        assert bits_equal(a, b), (W, H)
+        if W * H <= 100_000:
+            ref, _ = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=8)
+            assert bits_equal(ref, a), (W, H)
+    print("short division in use:", used)
+    assert used[(1, 1)] == 1                      # division by one
