@@ -266,7 +266,7 @@ def main():
             out["roofline"]["traffic"] = tr
             out["roofline"]["traffic_source"] = PROFILE
             out["roofline"]["hbm_GBps_from_traffic"] = tr / (kernel_ms * 1e-3) / 1e9
-            rc_ = profile_counters("pt_resolve_kernel", None)
+            rc_ = profile_counters("pt_accumulate_kernel", None) or profile_counters("pt_resolve_kernel", None)
             if rc_:   # the per-path results are read back once by the accumulation kernel
                 out["roofline"]["traffic_with_accumulation_kernel"] = tr + (2.0 * rc_["FETCH_SIZE"] + rc_["WRITE_SIZE"]) * 1024.0
             out["roofline"]["algorithmic_hbm_bytes"] = 2.0 * 16.0 * W * H   # one read-modify-write of the accumulator

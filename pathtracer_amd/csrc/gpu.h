@@ -27,7 +27,7 @@ struct RenderStats {
     bool exchange_on = false;             // the last launch ran the exchange variant
     uint32_t list_tiles = 0;              // 8x8 tiles whose camera rays test a candidate list in the last launch (0: all walk)
     uint32_t list_candidates = 0;         // entries of those lists
-    uint32_t sky_tiles = 0;               // tiles the last launch left to pt_sky_tiles_kernel (empty lists: sky only)
+    uint32_t sky_tiles = 0;               // tiles the last launch left to pt_accumulate_kernel (empty lists: sky only)
     bool short_div = false;               // pixel coordinates are divided by the verified short sequence (PixelDiv)
     uint32_t dropped_frames = 0;          // set by finish() when it fails: queued frames that were never added to the accumulator
 };

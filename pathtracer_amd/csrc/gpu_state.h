@@ -79,7 +79,7 @@ struct Device {
     uint32_t width = 0, height = 0, n_pix = 0;
     f4* accum = nullptr;
     uint32_t* pixel_hash = nullptr;
-    // Results of one launch, frame-major; added to the accumulator in frame order by pt_resolve_kernel on
+    // Results of one launch, frame-major; added to the accumulator in frame order by pt_accumulate_kernel on
     // the same stream.  (Running that kernel, or the next launch's path kernel, on a second stream under
     // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
     // way of the persistent kernel's workgroup placement.)
@@ -100,7 +100,7 @@ struct Device {
     bool lists_in_use = false;       // the last launch read the lists
     uint32_t list_counts[4] = {0, 0, 0, 0};  // host copy of list_count: tiles with a list, entries, tiles with an empty list
     bool perm_sky_last = false;      // tile_perm was made with these lists: the tiles with an empty list are its last ranks
-    uint32_t sky_tiles_last = 0;     // tiles the last launch left to pt_sky_tiles_kernel
+    uint32_t sky_tiles_last = 0;     // tiles the last launch left to pt_accumulate_kernel
     float rcp_w = 0.0f, rcp_h = 0.0f;  // 1 / width, 1 / height
     bool short_div = false;          // PixelDiv's short sequence verified for this width and height (resize)
     bool lists_valid = false;

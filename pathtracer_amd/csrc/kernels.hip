@@ -7,7 +7,7 @@
 //                           how many lanes wait for it
 //   pt_render_kernel        the same paths in plain lockstep (acquire -> camera -> whole BVH walk ->
 //                           scatter per iteration); kept as the simple reference for the scheduled one
-//   pt_resolve_kernel       adds the per-frame results to the accumulator in frame order
+//   pt_accumulate_kernel    adds the per-frame results to the accumulator in frame order
 //                           (compute.wgsl:418-421), which keeps sums bit-identical to a frame-by-frame run
 //   pt_tile_order_kernel    orders the 8x8 tiles by the rays they cost in the last launch
 #include <hip/hip_runtime.h>
@@ -278,7 +278,7 @@ __global__ void pt_tile_lists_kernel(const char* scene, SceneLayout L, Camera64 
     w4* out = reinterpret_cast<w4*>(lists + (size_t)t * TILE_LIST_WORDS);
     for (uint32_t k = 0; k < TILE_LIST_WORDS / 4u; k++) out[k] = w4{rec[4 * k], rec[4 * k + 1], rec[4 * k + 2], rec[4 * k + 3]};
     if (rec[0] != TILE_LIST_WALK) atomicAdd(count, 1u), atomicAdd(count + 1, rec[0]);  // statistics
-    if (rec[0] == 0u) atomicAdd(count + 2, 1u);  // tiles that show nothing but sky (pt_sky_tiles_kernel)
+    if (rec[0] == 0u) atomicAdd(count + 2, 1u);  // tiles that show nothing but sky (sky_block of pt_accumulate_kernel)
 }
 
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m) {
@@ -1058,19 +1058,18 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
 // (tile rank, slot), i.e. one wave per tile; at any moment all waves stream through the same frame.
 // (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
 // measured 6x slower at 3840x2160.)
-__global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
+__device__ __forceinline__ void resolve_block(uint32_t block, f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
                                   uint32_t tiles, uint32_t active_tiles, uint32_t n_frames, const uint32_t* tile_perm,
                                   unsigned long long* ray_total, float* tile_cost, uint32_t compact,
                                   const unsigned long long* gave_up, unsigned long long* launches_added) {
     // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
     // so nothing of this launch is added.
-    if (*gave_up) return;
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t gid = block * blockDim.x + threadIdx.x;
     if (gid == 0) atomicAdd(launches_added, 1ull);  // what finish() credits: launches whose results reached the accumulator
     const uint32_t rank = gid >> 6, slot = gid & 63u;
     unsigned long long rays = 0;
     uint32_t tile = 0;
-    if (rank < active_tiles) {  // ranks beyond belong to pt_sky_tiles_kernel; `tiles` is the stride of the layout
+    if (rank < active_tiles) {  // ranks beyond are sky tiles (sky_block); `tiles` is the stride of the layout
         tile = tile_perm ? tile_perm[rank] : rank;
         const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
         if (px < width && py < height) {
@@ -1118,7 +1117,7 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
     if ((threadIdx.x & 63u) == 0) {
         // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
         // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
-        if (rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+        if (rays) atomicAdd(ray_total + (size_t)(block % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
         if (tile_cost && rank < active_tiles) tile_cost[tile] = (float)rays;
     }
 }
@@ -1130,16 +1129,15 @@ __global__ void pt_resolve_kernel(f4* accum, const f4* results, uint32_t width, 
 // order.  Same arithmetic as the path kernels followed by the accumulation kernel (sky_pixel_frame), so the
 // texel's bits are the same.
 constexpr uint32_t SKY_FRAMES = 4;  // frames in flight per tile = waves per workgroup
-__global__ void __launch_bounds__(64 * SKY_FRAMES) pt_sky_tiles_kernel(f4* accum, Camera64 cam64, uint32_t width, uint32_t height,
+__device__ __forceinline__ void sky_block(uint32_t block, f4* accum, Camera64 cam64, uint32_t width, uint32_t height,
                                                                       uint32_t tiles_x, uint32_t first_rank, uint32_t n_frames,
                                                                       const uint32_t* tile_perm, const uint32_t* seeds,
                                                                       const uint32_t* pixel_hash, unsigned long long* ray_total,
                                                                       const unsigned long long* gave_up, float rcp_w, float rcp_h,
                                                                       uint32_t short_div) {
-    if (*gave_up) return;  // as pt_resolve_kernel: nothing of a launch whose path kernel gave up is added
     __shared__ float colour[SKY_FRAMES][3][64];
     const uint32_t slot = threadIdx.x & 63u, sub = threadIdx.x >> 6;
-    const uint32_t tile = tile_perm[first_rank + blockIdx.x];
+    const uint32_t tile = tile_perm[first_rank + block];
     const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
     const bool inside = px < width && py < height;  // the barriers below are reached by every lane
     const CameraRegs cam = load_camera(cam64);
@@ -1162,8 +1160,33 @@ __global__ void __launch_bounds__(64 * SKY_FRAMES) pt_sky_tiles_kernel(f4* accum
     if (sub == 0) {
         if (inside) accum[i] = a;
         const unsigned long long rays = wave_sum(inside ? (unsigned long long)n_frames : 0ull);  // one closest-hit query per path
-        if (slot == 0 && rays) atomicAdd(ray_total + (size_t)(blockIdx.x % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+        if (slot == 0 && rays) atomicAdd(ray_total + (size_t)(block % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
     }
+}
+
+
+// The accumulation of one launch as ONE kernel: `sky_blocks` of its workgroups each take a sky tile (sky_block:
+// bound by vector instructions), the others 256 texels of the buffered results (resolve_block: bound by HBM
+// reads).  The two kinds are interleaved in proportion to their numbers, so that -- workgroups being dispatched in
+// index order -- both are in flight on every compute unit from the first to the last moment of the grid.
+__global__ void __launch_bounds__(256) pt_accumulate_kernel(f4* accum, const f4* results, Camera64 cam64, uint32_t width, uint32_t height,
+                                                           uint32_t tiles_x, uint32_t tiles, uint32_t active_tiles, uint32_t n_frames,
+                                                           const uint32_t* tile_perm, const uint32_t* seeds, const uint32_t* pixel_hash,
+                                                           unsigned long long* ray_total, float* tile_cost, uint32_t compact,
+                                                           const unsigned long long* gave_up, unsigned long long* launches_added,
+                                                           uint32_t sky_blocks, float rcp_w, float rcp_h, uint32_t short_div) {
+    // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
+    // so nothing of this launch is added.
+    if (*gave_up) return;
+    // sky tiles among the first i workgroups: floor(i * sky_blocks / gridDim.x)
+    const uint32_t before = (uint32_t)((uint64_t)blockIdx.x * sky_blocks / gridDim.x);
+    const uint32_t upto = (uint32_t)(((uint64_t)blockIdx.x + 1u) * sky_blocks / gridDim.x);
+    if (upto > before)
+        sky_block(before, accum, cam64, width, height, tiles_x, active_tiles, n_frames, tile_perm, seeds, pixel_hash, ray_total,
+                  gave_up, rcp_w, rcp_h, short_div);
+    else
+        resolve_block(blockIdx.x - before, accum, results, width, height, tiles_x, tiles, active_tiles, n_frames, tile_perm, ray_total,
+                      tile_cost, compact, gave_up, launches_added);
 }
 
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
@@ -1172,7 +1195,7 @@ constexpr int ORDER_BLK = 1024;
 // rank_chunk[r]: units a chunk starting in the r-th tile of that order should hold so that it costs about
 // `chunk_rays` rays (the cost of one unit of a tile = its measured rays / frames_measured).
 // With `lists` (the camera rays' candidate lists) the tiles whose list is empty -- sky and nothing else -- come
-// last, whatever they cost: launches that leave them to pt_sky_tiles_kernel end their queue before them.
+// last, whatever they cost: launches that leave them to the sky blocks of pt_accumulate_kernel end their queue before them.
 __global__ void __launch_bounds__(ORDER_BLK) pt_tile_order_kernel(const float* tile_cost, uint32_t tiles, uint32_t* perm,
                                                                  uint16_t* rank_chunk, float frames_measured,
                                                                  float chunk_rays, uint32_t chunk_max, const uint32_t* lists) {
@@ -1974,7 +1997,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 63u);
         P.compact = measure ? 0u : 1u;
         // Tiles that show nothing but sky (empty candidate lists; last in an order made with the lists) are left to
-        // pt_sky_tiles_kernel on launches of the plain kind: one sample per path, no counting, no cost measurement.
+        // the sky blocks of pt_accumulate_kernel on launches of the plain kind: one sample per path, no counting, no cost measurement.
         uint32_t sky_tiles = 0;
         if (sw.sky_tiles && use_perm && d->perm_sky_last && d->lists_in_use && !measure && !cfg.count && cfg.samples == 1 &&
             d->list_counts[2] < tiles)
@@ -1993,16 +2016,12 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
             return false;
         // accumulate in frame order (same stream: launches of one context never overlap)
         if (!timed_launch(true, [&]() {
-                hipLaunchKernelGGL(pt_resolve_kernel, dim3((active_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum,
-                                   P.frame_out, d->width, d->height, tiles_x, tiles, active_tiles, nb, P.tile_perm, d->ray_slots,
-                                   measure ? d->tile_cost : nullptr, P.compact, d->counters + 10, d->counters + 9);
+                static_assert(64 * SKY_FRAMES == 256, "sky tiles and buffered results share one workgroup size");
+                hipLaunchKernelGGL(pt_accumulate_kernel, dim3(sky_tiles + (active_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream,
+                                   d->accum, P.frame_out, cam, d->width, d->height, tiles_x, tiles, active_tiles, nb, P.tile_perm, P.seeds,
+                                   d->pixel_hash, d->ray_slots, measure ? d->tile_cost : nullptr, P.compact, d->counters + 10,
+                                   d->counters + 9, sky_tiles, P.rcp_w, P.rcp_h, P.short_div);
                 PT_HIP(hipGetLastError());
-                if (sky_tiles) {
-                    hipLaunchKernelGGL(pt_sky_tiles_kernel, dim3(sky_tiles), dim3(64 * SKY_FRAMES), 0, d->stream, d->accum, cam,
-                                       d->width, d->height, tiles_x, active_tiles, nb, d->tile_perm, P.seeds, d->pixel_hash,
-                                       d->ray_slots, d->counters + 10, P.rcp_w, P.rcp_h, P.short_div);
-                    PT_HIP(hipGetLastError());
-                }
                 return true;
             }))
             return false;

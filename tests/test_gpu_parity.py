@@ -673,7 +673,7 @@ def test_camera_ray_candidate_lists_are_bit_identical(pa, orc, monkeypatch):
 def test_sky_only_tiles_accumulated_per_pixel_are_bit_identical(pa, orc, monkeypatch):
     # Tiles whose candidate list is empty show nothing but sky.  Once the tile order has been measured (a launch of
     # at least 8 frames) they sit at the end of the order, and launches of the plain kind leave them to
-    # pt_sky_tiles_kernel: one lane per pixel adds the frames in order, no result buffer.  Same bits as the oracle,
+    # pt_accumulate_kernel: one lane per pixel adds the frames in order, no result buffer.  Same bits as the oracle,
     # same ray count, whether the split is on or off, over several launches and with queued calls.
     for name, (W, H) in (("scene1.ron", (320, 180)), ("scene2.ron", (203, 117))):
         path = os.path.join(FIXTURES, name)
