@@ -1,5 +1,7 @@
 """Development soak: random scenes (tests/conftest.py) x three trees on the GPU against the oracle.
-usage: python tools/soak.py <count> [<first seed>]"""
+usage: python tools/soak.py <count> [<first seed>]
+SOAK_FRAMES=n (default 2): frames per render; with n >= 10 the first 9 go in one call (which measures the tile order)
+and the rest in a second one, so that the sky-tile split of the accumulation kernel is exercised too."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
@@ -15,10 +17,16 @@ for seed in range(start, start + int(sys.argv[1])):
     for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE)), (False, (pa.BVH_LBVH,))):
         sc = random_scene(pa, seed, duplicates=dup)
         osc = oracle_scene(orc, sc)
-        ref, st = orc.render(osc, osc.camera(W, H), W, H, [seed, 7], samples=samples, depth=depth, threads=16)
+        nf = int(os.environ.get("SOAK_FRAMES", 2))
+        seeds = [seed, 7] + [seed * 31 + k for k in range(nf - 2)]
+        ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, samples=samples, depth=depth, threads=16)
         for mode in modes:
             with pa.Renderer(sc, pa.Settings(samples, depth), W, H, bvh_mode=mode) as r:
-                r.render(seeds=[seed, 7])
+                if nf >= 10:
+                    r.render(seeds=seeds[:9])
+                    r.render(seeds=seeds[9:])
+                else:
+                    r.render(seeds=seeds)
                 if not bits_equal(ref, r.read_accum()) or r.stats()["rays"] != st["rays"]:
                     bad += 1
                     print("MISMATCH seed", seed, "mode", mode, flush=True)
