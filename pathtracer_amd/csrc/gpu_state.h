@@ -51,6 +51,9 @@ struct Switches {
     bool exchange_global = true;                // MI355PT_XCHG_GLOBAL=0: no exchange variant for trees in global memory
     bool exchange = true;                       // MI355PT_XCHG=0: never the exchange variant of the scheduled kernel
     uint32_t xthr[6] = {10, 6, 24, 24, 16, 32}; // MI355PT_XCHG_SCHED: step thresholds of the exchange variant (65: never locally)
+    uint32_t measure_every = 64;                // MI355PT_MEASURE_EVERY: the tile costs are measured again on every n-th launch
+    bool defer_resolve = true;                  // MI355PT_DEFER_RESOLVE=0: every launch's results are added by a kernel right behind it
+    uint32_t resolve_wgs = 16;                  // MI355PT_RESOLVE_WGS: workgroups of a path kernel that add the previous launch's results
     bool short_div = true;                      // MI355PT_SHORT_DIV=0: pixel coordinates are always divided the general way
     bool sky_tiles = true;                      // MI355PT_SKY_TILES=0: tiles that show only sky go through the path kernel like the rest
     bool tile_lists = true;                     // MI355PT_TILE_LISTS=0: camera rays walk the tree like every other ray
@@ -84,7 +87,16 @@ struct Device {
     // the tail of the current one was measured 5-10 % slower on MI355X: concurrent kernels get in the
     // way of the persistent kernel's workgroup placement.)
     f4* frame_buf = nullptr;
-    size_t frame_cap = 0;  // in f4 elements
+    size_t frame_cap = 0;  // in f4 elements; two halves, written by alternate launches
+    uint32_t frame_half = 0;  // the half the next launch writes
+    // Buffered results of the last launch that are not in the accumulator yet: the next launch's path kernel adds
+    // them in its prologue, finish() (or a launch that cannot) with a kernel of its own.
+    struct PendingResolve {
+        bool active = false;
+        const f4* results = nullptr;
+        const uint32_t* perm = nullptr;
+        uint32_t frames = 0, tiles = 0, active_tiles = 0;
+    } pending_resolve;
     // Cost-ordered work: rays per tile of the last measuring launch, tiles sorted by it, and what it was measured for
     float* tile_cost = nullptr;    // [tiles]
     uint32_t* tile_perm = nullptr; // [tiles]

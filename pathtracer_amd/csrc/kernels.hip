@@ -221,6 +221,12 @@ struct RenderParams {
     const uint32_t* tile_lists;  // pt_render_sched_kernel: per tile TILE_LIST_WORDS words, the candidates of its camera rays (null: none)
     float rcp_w, rcp_h;          // 1 / width, 1 / height
     uint32_t short_div;          // 1: the short division by width and height was verified for this image size (PixelDiv)
+    // The buffered results of the PREVIOUS launch, still to be added to the accumulator (null: none): the first
+    // `resolve_wgs` workgroups of this launch add them before they take paths (see the kernel's prologue).
+    f4* accum;
+    const f4* prev_results;
+    const uint32_t* prev_perm;
+    uint32_t prev_frames, prev_active_tiles, resolve_wgs;
 };
 
 // Paths waiting for a scatter step, parked in LDS by the exchange variant: per class (lambertian / metal, glass)
@@ -492,6 +498,75 @@ __global__ void __launch_bounds__(BLK) pt_render_kernel(const RenderParams P) {
     }
 }
 
+// accum[p] += vec4(result[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side
+// (total, and per tile into `tile_cost` when given: the input of pt_tile_order_kernel).  Results lie in
+// [frame][tile rank][slot] order, ranks being those of the launch that produced them: one thread per
+// (tile rank, slot), i.e. one wave per tile; at any moment all waves stream through the same frame.
+// (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
+// measured 6x slower at 3840x2160.)
+// `block` / `thread`: which 256 texels (in rank order) and which of them; the callers' workgroups may be larger.
+__device__ __forceinline__ void resolve_block(uint32_t block, uint32_t thread, f4* accum, const f4* results, uint32_t width, uint32_t height,
+                                              uint32_t tiles_x, uint32_t tiles, uint32_t active_tiles, uint32_t n_frames,
+                                              const uint32_t* tile_perm, unsigned long long* ray_total, float* tile_cost, uint32_t compact,
+                                              const unsigned long long* gave_up, unsigned long long* launches_added) {
+    const uint32_t gid = block * 256u + thread;
+    if (gid == 0) atomicAdd(launches_added, 1ull);  // what finish() credits: launches whose results reached the accumulator
+    const uint32_t rank = gid >> 6, slot = gid & 63u;
+    unsigned long long rays = 0;
+    uint32_t tile = 0;
+    if (rank < active_tiles) {  // ranks beyond are sky tiles (sky_block); `tiles` is the stride of the layout
+        tile = tile_perm ? tile_perm[rank] : rank;
+        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
+        if (px < width && py < height) {
+            const uint32_t i = py * width + px;
+            f4 a = accum[i];
+            const f4* src = results + (size_t)rank * 64u + slot;
+            const size_t frame_stride = (size_t)tiles * 64u;
+            if (compact) {  // 12-byte results; the path kernel has counted the rays
+                const float* c = reinterpret_cast<const float*>(results) + ((size_t)rank * 64u + slot) * 3u;
+                const size_t stride = frame_stride * 3u;
+                // the sums are sequential by definition, the fetches are not: eight frames' results are requested
+                // before the first is added (one fetch at a time leaves a wave idle for a memory latency per frame)
+                uint32_t f = 0;
+                for (; f + 8u <= n_frames; f += 8u) {
+                    float v[8][3];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; k++) {
+                        const float* s = c + (size_t)(f + k) * stride;
+                        v[k][0] = __builtin_nontemporal_load(s), v[k][1] = __builtin_nontemporal_load(s + 1), v[k][2] = __builtin_nontemporal_load(s + 2);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 8u; k++) a.x += v[k][0], a.y += v[k][1], a.z += v[k][2], a.w += 0.0f;
+                }
+                for (; f < n_frames; f++) {
+                    const float* s = c + (size_t)f * stride;
+                    a.x += s[0];
+                    a.y += s[1];
+                    a.z += s[2];
+                    a.w += 0.0f;
+                }
+            } else {
+                for (uint32_t f = 0; f < n_frames; f++) {
+                    f4 s = src[(size_t)f * frame_stride];
+                    a.x += s.x;
+                    a.y += s.y;
+                    a.z += s.z;
+                    a.w += 0.0f;
+                    rays += (unsigned long long)s.w;
+                }
+            }
+            accum[i] = a;
+        }
+    }
+    rays = wave_sum(rays);
+    if ((thread & 63u) == 0) {
+        // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
+        // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
+        if (rays) atomicAdd(ray_total + (size_t)(block % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
+        if (tile_cost && rank < active_tiles) tile_cost[tile] = (float)rays;
+    }
+}
+
 // Wave-scheduled variant.  Every lane is a small state machine kept in Walk::cur -- interior node
 // pending, leaf pending, walk finished, one of three scatter classes pending, idle (needs a path or a
 // camera ray), exited -- and the wave runs one kind of step at a time, only when enough lanes wait
@@ -591,6 +666,22 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
     bool exhausted = false;
     bool force = false;
 #define PT_THR(ph) (force ? 1u : P.thr[ph])
+
+    // Prologue: the buffered results of the previous launch are added to the accumulator by the first few workgroups
+    // of this one, before they take paths.  That work is bound by HBM reads and barely issues instructions, so it
+    // runs beside the other waves' path work for free, where a kernel of its own between two path kernels costs its
+    // full duration (and a kernel on a second queue beside the path kernel costs the path kernel a third of its rate).
+    if constexpr (XCHG && FAST) {
+        KernargView Q = kernarg_view();
+        const uint32_t wgs = min(Q->resolve_wgs, gridDim.x);  // a small launch has fewer workgroups than that
+        if (Q->prev_results != nullptr && blockIdx.x < wgs && P.counters[10] == 0ull) {
+            const uint32_t blocks = (Q->prev_active_tiles * 64u + 255u) / 256u;
+            for (uint32_t b = blockIdx.x * (BLK / 256u) + (threadIdx.x >> 8); b < blocks; b += wgs * (BLK / 256u))
+                resolve_block(b, threadIdx.x & 255u, reinterpret_cast<f4*>(Q->accum), Q->prev_results, Q->width, Q->height, Q->tiles_x,
+                              Q->tiles_per_frame, Q->prev_active_tiles, Q->prev_frames, Q->prev_perm, Q->ray_slots, nullptr, 1u,
+                              P.counters + 10, P.counters + 9);
+        }
+    }
 
     // One sample of a path has ended with `radiance`.
     auto finish_sample = [&](V3 radiance) {
@@ -1052,76 +1143,6 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
 }
 
 
-// accum[p] += vec4(result[f][p].rgb, 0) for f = 0..n_frames-1 in order; ray counts summed on the side
-// (total, and per tile into `tile_cost` when given: the input of pt_tile_order_kernel).  Results lie in
-// [frame][tile rank][slot] order, ranks being those of the launch that produced them: one thread per
-// (tile rank, slot), i.e. one wave per tile; at any moment all waves stream through the same frame.
-// (A [tile rank][frame][slot] layout makes the waves' simultaneous reads a power-of-two stride apart:
-// measured 6x slower at 3840x2160.)
-__device__ __forceinline__ void resolve_block(uint32_t block, f4* accum, const f4* results, uint32_t width, uint32_t height, uint32_t tiles_x,
-                                  uint32_t tiles, uint32_t active_tiles, uint32_t n_frames, const uint32_t* tile_perm,
-                                  unsigned long long* ray_total, float* tile_cost, uint32_t compact,
-                                  const unsigned long long* gave_up, unsigned long long* launches_added) {
-    // The path kernel's watchdog fired (now or in an earlier launch of the queue): its results are incomplete,
-    // so nothing of this launch is added.
-    const uint32_t gid = block * blockDim.x + threadIdx.x;
-    if (gid == 0) atomicAdd(launches_added, 1ull);  // what finish() credits: launches whose results reached the accumulator
-    const uint32_t rank = gid >> 6, slot = gid & 63u;
-    unsigned long long rays = 0;
-    uint32_t tile = 0;
-    if (rank < active_tiles) {  // ranks beyond are sky tiles (sky_block); `tiles` is the stride of the layout
-        tile = tile_perm ? tile_perm[rank] : rank;
-        const uint32_t px = (tile % tiles_x) * 8u + (slot & 7u), py = (tile / tiles_x) * 8u + (slot >> 3);
-        if (px < width && py < height) {
-            const uint32_t i = py * width + px;
-            f4 a = accum[i];
-            const f4* src = results + (size_t)rank * 64u + slot;
-            const size_t frame_stride = (size_t)tiles * 64u;
-            if (compact) {  // 12-byte results; the path kernel has counted the rays
-                const float* c = reinterpret_cast<const float*>(results) + ((size_t)rank * 64u + slot) * 3u;
-                const size_t stride = frame_stride * 3u;
-                // the sums are sequential by definition, the fetches are not: eight frames' results are requested
-                // before the first is added (one fetch at a time leaves a wave idle for a memory latency per frame)
-                uint32_t f = 0;
-                for (; f + 8u <= n_frames; f += 8u) {
-                    float v[8][3];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; k++) {
-                        const float* s = c + (size_t)(f + k) * stride;
-                        v[k][0] = __builtin_nontemporal_load(s), v[k][1] = __builtin_nontemporal_load(s + 1), v[k][2] = __builtin_nontemporal_load(s + 2);
-                    }
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; k++) a.x += v[k][0], a.y += v[k][1], a.z += v[k][2], a.w += 0.0f;
-                }
-                for (; f < n_frames; f++) {
-                    const float* s = c + (size_t)f * stride;
-                    a.x += s[0];
-                    a.y += s[1];
-                    a.z += s[2];
-                    a.w += 0.0f;
-                }
-            } else {
-                for (uint32_t f = 0; f < n_frames; f++) {
-                    f4 s = src[(size_t)f * frame_stride];
-                    a.x += s.x;
-                    a.y += s.y;
-                    a.z += s.z;
-                    a.w += 0.0f;
-                    rays += (unsigned long long)s.w;
-                }
-            }
-            accum[i] = a;
-        }
-    }
-    rays = wave_sum(rays);
-    if ((threadIdx.x & 63u) == 0) {
-        // one atomic per wave: spread over RAY_SLOTS addresses in different cache lines (atomics on one
-        // address run one at a time, ~12 ns each: 130 k of them cost 1.5 ms at 3840x2160)
-        if (rays) atomicAdd(ray_total + (size_t)(block % RAY_SLOTS) * RAY_SLOT_STRIDE, rays);
-        if (tile_cost && rank < active_tiles) tile_cost[tile] = (float)rays;
-    }
-}
-
 // The tiles at ranks [first_rank, tiles) of the order show nothing but sky (their candidate lists are empty): every
 // path there is one camera ray and the sky colour.  No queue and no result buffer: a workgroup owns a tile, its
 // four waves work out the colours of four consecutive frames of the tile's 64 pixels side by side (the colours
@@ -1185,8 +1206,8 @@ __global__ void __launch_bounds__(256) pt_accumulate_kernel(f4* accum, const f4*
         sky_block(before, accum, cam64, width, height, tiles_x, active_tiles, n_frames, tile_perm, seeds, pixel_hash, ray_total,
                   gave_up, rcp_w, rcp_h, short_div);
     else
-        resolve_block(blockIdx.x - before, accum, results, width, height, tiles_x, tiles, active_tiles, n_frames, tile_perm, ray_total,
-                      tile_cost, compact, gave_up, launches_added);
+        resolve_block(blockIdx.x - before, threadIdx.x, accum, results, width, height, tiles_x, tiles, active_tiles, n_frames, tile_perm,
+                      ray_total, tile_cost, compact, gave_up, launches_added);
 }
 
 // Tiles (8x8 pixels) ordered by decreasing cost (rays traced in them during the last launch): one
@@ -1277,6 +1298,9 @@ static void read_switches(Switches& s) {
         const char* nodes = getenv("MI355PT_NODES");
         s.ordered_global = !(nodes && strcmp(nodes, "plain") == 0);
     }
+    s.measure_every = (uint32_t)std::max(1l, env_long("MI355PT_MEASURE_EVERY", 64));
+    s.defer_resolve = env_long("MI355PT_DEFER_RESOLVE", 1) != 0;
+    s.resolve_wgs = (uint32_t)std::min(4096l, std::max(1l, env_long("MI355PT_RESOLVE_WGS", 16)));
     s.short_div = env_long("MI355PT_SHORT_DIV", 1) != 0;
     s.sky_tiles = env_long("MI355PT_SKY_TILES", 1) != 0;
     s.tile_lists = env_long("MI355PT_TILE_LISTS", 1) != 0;
@@ -1636,9 +1660,24 @@ bool render(Device* d, const Camera64& cam, const RenderConfig& cfg, const uint3
     return enqueue(d, cam, cfg, seeds, n_frames, stats, err) && finish(d, stats, err);
 }
 
+// Adds the buffered results that no path kernel's prologue has taken (the last launch of a queue, or a launch
+// followed by one that has no prologue) with a kernel of their own.
+static bool launch_pending_resolve(Device* d, std::string& err) {
+    Device::PendingResolve& p = d->pending_resolve;
+    if (!p.active) return true;
+    const uint32_t tiles_x = (d->width + 7) / 8;
+    hipLaunchKernelGGL(pt_accumulate_kernel, dim3((p.active_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream, d->accum, p.results,
+                       Camera64{}, d->width, d->height, tiles_x, p.tiles, p.active_tiles, p.frames, p.perm, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, d->ray_slots, (float*)nullptr, 1u, d->counters + 10, d->counters + 9, 0u, 0.0f, 0.0f, 0u);
+    PT_HIP(hipGetLastError());
+    p.active = false;
+    return true;
+}
+
 bool finish(Device* d, RenderStats& stats, std::string& err) {
     if (!d->in_flight) return true;
     DeviceGuard guard(d->id);
+    const bool flushed = launch_pending_resolve(d, err);  // before the wait below; a failure is reported after the clean-up
     // whatever happens below, the queue is empty afterwards: a failed call must not poison the next one
     struct Reset {
         Device* d;
@@ -1652,6 +1691,7 @@ bool finish(Device* d, RenderStats& stats, std::string& err) {
         }
     } reset{d};
     PT_SYNC_ALL(d);
+    if (!flushed) return false;
     for (auto& t : d->timed) {
         float ms = 0.0f;
         PT_HIP(hipEventElapsedTime(&ms, t.begin, t.end));
@@ -1744,7 +1784,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
                 const size_t held = d->frame_cap * sizeof(f4);  // ours already
-                budget = std::min(budget, (free_b + held) / 4);
+                budget = std::min(budget, (free_b + held) / 8);  // two halves: together at most a quarter
             }
         }
         size_t by_mem = budget / ((size_t)tiles * 64u * sizeof(f4));
@@ -1759,13 +1799,14 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
     };
     if (batch) batch = balanced(n_frames, batch);
     size_t need = (size_t)batch * tiles * 64u;  // whole tiles: [frame][tile rank][64 slots]
-    if (!fixed && need > d->frame_cap) {
+    if (!fixed && 2u * need > d->frame_cap) {
         if (!finish(d, stats, err)) return false;  // nothing may still read or write the old buffer
         (void)hipFree(d->frame_buf);
         d->frame_buf = nullptr;
         d->frame_cap = 0;
-        PT_HIP(hipMalloc(&d->frame_buf, need * sizeof(f4)));
-        d->frame_cap = need;
+        PT_HIP(hipMalloc(&d->frame_buf, 2u * need * sizeof(f4)));
+        d->frame_cap = 2u * need;
+        d->frame_half = 0;
     }
     if (!fixed && n_frames > d->seeds_cap) {
         if (!finish(d, stats, err)) return false;
@@ -1994,7 +2035,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         // the refresh only guards against a first measurement on an unusually short launch); measuring needs
         // the ray count per path (16-byte results, the kernel's general instance: 10-20 % slower), all other
         // launches write and re-read 12 bytes per path.
-        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure >= 63u);
+        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure + 1u >= sw.measure_every);
         P.compact = measure ? 0u : 1u;
         // Tiles that show nothing but sky (empty candidate lists; last in an order made with the lists) are left to
         // the sky blocks of pt_accumulate_kernel on launches of the plain kind: one sample per path, no counting, no cost measurement.
@@ -2007,6 +2048,23 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         P.small_ids = (P.total_units < (1u << 24) && tiles < (1u << 24)) ? 1u : 0u;
         d->sky_tiles_last = sky_tiles;
         P.ray_slots = d->ray_slots;
+        P.accum = d->accum;
+        // The buffered results of the previous launch: added by this launch's path kernel in its prologue when the
+        // instance that runs has one (exchange variant, one sample per path, 12-byte results), else by a kernel of
+        // their own now.  A measuring launch rewrites the tile order those results are laid out by: flush first.
+        const bool has_prologue = !lockstep && !cfg.count && cfg.samples == 1 && P.compact && P.pool_off != 0u && block == 1024u &&
+                                  (scene_mode == SCENE_LDS || scene_mode == SCENE_GLOBAL || scene_mode == SCENE_GLOBAL_ORDERED);
+        P.prev_results = nullptr;
+        if (d->pending_resolve.active) {
+            if (has_prologue && !measure) {
+                const Device::PendingResolve& pr = d->pending_resolve;
+                P.prev_results = pr.results, P.prev_perm = pr.perm, P.prev_frames = pr.frames, P.prev_active_tiles = pr.active_tiles;
+                P.resolve_wgs = sw.resolve_wgs;
+            } else if (!timed_launch(true, [&]() { return launch_pending_resolve(d, err); })) {
+                return false;
+            }
+        }
+        if (!fixed) P.frame_out = d->frame_buf + (size_t)d->frame_half * (d->frame_cap / 2u);
         PT_HIP(hipMemsetAsync(P.work_counter, 0, 4, d->stream));
         if (!timed_launch(false, [&]() {
                 if (block == 512) return launch_render_blk<512>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
@@ -2014,10 +2072,18 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
                 return launch_render_blk<256>(d, P, lds_bytes, scene_mode, cfg.count, lockstep, err);
             }))
             return false;
-        // accumulate in frame order (same stream: launches of one context never overlap)
-        if (!timed_launch(true, [&]() {
+        d->pending_resolve.active = false;  // taken by the prologue of the kernel just queued (or flushed above)
+        // Accumulate in frame order (same stream: launches of one context never overlap).  The buffered results wait
+        // for the next launch's prologue (or finish()) unless this launch measures tile costs; the sky tiles, which
+        // need no buffer, are added now.
+        // (only behind a kernel that has the prologue itself: the next launch then has it too; without one the
+        // buffered results are better added beside the sky tiles, in the one grid below)
+        const bool defer = sw.defer_resolve && !fixed && !measure && has_prologue;
+        const uint32_t resolve_blocks = defer ? 0u : (active_tiles * 64u + 255u) / 256u;
+        if (sky_tiles + resolve_blocks > 0u &&
+            !timed_launch(true, [&]() {
                 static_assert(64 * SKY_FRAMES == 256, "sky tiles and buffered results share one workgroup size");
-                hipLaunchKernelGGL(pt_accumulate_kernel, dim3(sky_tiles + (active_tiles * 64u + 255u) / 256u), dim3(256), 0, d->stream,
+                hipLaunchKernelGGL(pt_accumulate_kernel, dim3(sky_tiles + resolve_blocks), dim3(256), 0, d->stream,
                                    d->accum, P.frame_out, cam, d->width, d->height, tiles_x, tiles, active_tiles, nb, P.tile_perm, P.seeds,
                                    d->pixel_hash, d->ray_slots, measure ? d->tile_cost : nullptr, P.compact, d->counters + 10,
                                    d->counters + 9, sky_tiles, P.rcp_w, P.rcp_h, P.short_div);
@@ -2025,6 +2091,12 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
                 return true;
             }))
             return false;
+        if (defer) {
+            d->pending_resolve.active = true;
+            d->pending_resolve.results = P.frame_out, d->pending_resolve.perm = P.tile_perm;
+            d->pending_resolve.frames = nb, d->pending_resolve.tiles = tiles, d->pending_resolve.active_tiles = active_tiles;
+            d->frame_half ^= 1u;
+        }
         if (measure) {
             hipLaunchKernelGGL(pt_tile_order_kernel, dim3(1), dim3(ORDER_BLK), 0, d->stream, d->tile_cost, tiles,
                                d->tile_perm, d->rank_chunk, (float)nb, chunk_rays, P.chunk_max,

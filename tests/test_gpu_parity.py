@@ -724,3 +724,42 @@ def test_short_pixel_division_is_verified_and_changes_no_bit(pa, orc, monkeypatc
             assert bits_equal(ref, a), (W, H)
     print("short division in use:", used)
     assert used[(1, 1)] == 1                      # division by one
+
+
+def test_results_added_by_the_next_launch_are_bit_identical(pa, orc, monkeypatch):
+    # Behind a path kernel of the exchange kind the buffered results wait, and the next launch's path kernel adds
+    # them in its prologue (a few of its workgroups, before they take paths); whatever is still waiting when the
+    # queue is joined, when a launch follows that has no prologue, or when a launch is about to measure the tile
+    # order anew, is added by a kernel of its own.  Several launches per call, queued calls, a re-measurement every
+    # fourth launch, a clear and a settings change in between, a tiny image whose launches have fewer workgroups
+    # than the prologue would use, all against the oracle; and the same with the deferral off.
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    monkeypatch.setenv("MI355PT_BLOCK", "1024")          # the exchange kind also for these short launches
+    monkeypatch.setenv("MI355PT_MAX_BATCH", "10")        # several launches per call
+    monkeypatch.setenv("MI355PT_MEASURE_EVERY", "4")
+    seeds = np.arange(1, 65, dtype=np.uint32) * np.uint32(747796405)
+    for W, H in ((200, 112), (16, 9)):
+        ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, threads=16)
+        ref3, _ = orc.render(osc, osc.camera(W, H), W, H, seeds[:3], threads=16)
+        for defer in ("1", "0"):
+            monkeypatch.setenv("MI355PT_DEFER_RESOLVE", defer)
+            with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+                r.render(seeds=seeds[:20])                 # 10 + 10 frames: the first measures the tile order
+                r.render(seeds=seeds[20:27], wait=False)   # 7
+                r.render(seeds=seeds[27:50], wait=False)   # 8 + 8 + 7, one of them measures again
+                r.render(seeds=seeds[50:])                 # 7 + 7
+                s = r.stats()
+                assert s["exchange_on"] == 1 and s["launches"] == 8
+                assert bits_equal(ref, r.read_accum()) and s["rays"] == st["rays"] and r.samples() == len(seeds), (W, H, defer)
+                r.clear()
+                r.render(seeds=seeds[:3], wait=False)      # something waits while the settings change
+                r.reload_settings(pa.Settings(2, 50))      # two samples per path: a kernel without a prologue follows
+                r.render(seeds=seeds[3:4], wait=False)
+                r.clear()
+                r.render(seeds=seeds[:3])
+                assert r.samples() == 3
+            with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
+                r.render(seeds=seeds[:3], wait=False)
+                got = r.read_accum()                        # joins: the waiting results are added first
+                assert bits_equal(ref3, got), (W, H, defer)
