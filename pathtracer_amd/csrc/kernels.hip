@@ -1677,7 +1677,20 @@ static bool launch_pending_resolve(Device* d, std::string& err) {
 bool finish(Device* d, RenderStats& stats, std::string& err) {
     if (!d->in_flight) return true;
     DeviceGuard guard(d->id);
-    const bool flushed = launch_pending_resolve(d, err);  // before the wait below; a failure is reported after the clean-up
+    // what still waits for a prologue is added now, before the wait below (timed like every accumulation; a failure
+    // is reported after the clean-up)
+    bool flushed = true;
+    if (d->pending_resolve.active) {
+        hipEvent_t b = take_event(d), e = take_event(d);
+        const bool timed = b && e && hipEventRecord(b, d->stream) == hipSuccess;
+        flushed = launch_pending_resolve(d, err);
+        if (timed && flushed && hipEventRecord(e, d->stream) == hipSuccess) {
+            d->timed.push_back(Device::Timed{b, e, true});
+        } else {
+            if (b) d->event_pool.push_back(b);
+            if (e) d->event_pool.push_back(e);
+        }
+    }
     // whatever happens below, the queue is empty afterwards: a failed call must not poison the next one
     struct Reset {
         Device* d;
