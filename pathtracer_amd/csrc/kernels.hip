@@ -2033,8 +2033,19 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         d->timed.push_back(Device::Timed{b, e, resolve});
         return true;
     };
-    for (uint32_t f0 = 0; f0 < n_frames; f0 += batch) {
-        const uint32_t nb = std::min(batch, n_frames - f0);
+    // A launch that measures the tile costs runs the kernel's general instance with 16-byte results, about twice the
+    // time per frame, and the costs are a property of scene and camera, not of the frames: when one is due it gets
+    // MEASURE_FRAMES frames of its own and the rest of the call is spread over launches of the plain kind (a
+    // 1000-frame call at 1280x720 used to measure on its first 500 frames).
+    constexpr uint32_t MEASURE_FRAMES = 16;
+    for (uint32_t f0 = 0, nb = 0; f0 < n_frames; f0 += nb) {
+        nb = std::min(batch, n_frames - f0);
+        const bool measure_due = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure + 1u >= sw.measure_every);
+        if (measure_due && nb > MEASURE_FRAMES) {
+            nb = MEASURE_FRAMES;
+            const uint32_t rest = n_frames - f0 - nb;
+            if (rest) batch = balanced(rest, batch);  // the rest in equal launches, none longer than the buffers were sized for
+        }
         P.frame_out = reinterpret_cast<f4*>(frame_buf);
         P.total_units = nb * tiles;
         P.n_frames = nb;
@@ -2048,7 +2059,7 @@ static bool enqueue_in(Device* d, const Workspace* fixed, const Camera64& cam, c
         // the refresh only guards against a first measurement on an unusually short launch); measuring needs
         // the ray count per path (16-byte results, the kernel's general instance: 10-20 % slower), all other
         // launches write and re-read 12 bytes per path.
-        const bool measure = !fixed && order_tiles && nb >= 8u && (!use_perm || d->since_measure + 1u >= sw.measure_every);
+        const bool measure = measure_due;
         P.compact = measure ? 0u : 1u;
         // Tiles that show nothing but sky (empty candidate lists; last in an order made with the lists) are left to
         // the sky blocks of pt_accumulate_kernel on launches of the plain kind: one sample per path, no counting, no cost measurement.
