@@ -197,7 +197,7 @@ def test_frame_order_and_batching_do_not_change_bits(pa, monkeypatch):
     with pa.Renderer(sc, pa.Settings(), W, H) as r:
         r.render(seeds=seeds)
         one = r.read_accum()
-        assert r.stats()["launches"] == 1
+        assert r.stats()["launches"] == 2             # 16 frames that measure the tile costs, then the other 54
         r.clear()
         r.render(seeds=seeds[:33])
         r.render(seeds=seeds[33:34])
@@ -316,7 +316,8 @@ def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
         r.wait()                                          # joining twice is harmless
     assert bits_equal(blocking, queued)
     assert st_q["rays"] == st_b["rays"] and st_q["paths"] == st_b["paths"]
-    assert st_q["launches"] == 6 and st_q["render_ms"] > 0 and st_q["resolve_ms"] > 0
+    # 70 frames = 16 that measure the tile costs + 2 x 27; then one launch per call
+    assert st_q["launches"] == 7 and st_q["render_ms"] > 0 and st_q["resolve_ms"] > 0
 
 
 @pytest.mark.parametrize("block", range(4))
