@@ -249,6 +249,9 @@ constexpr uint32_t POOL_TUNING[4] = {PT_POOL_TUNING};
 #endif
 constexpr uint32_t POOL_MIN_OPAQUE = POOL_TUNING[0], POOL_MIN_GLASS = POOL_TUNING[1];
 constexpr uint32_t POOL_DEP_MIN_OPAQUE = POOL_TUNING[2], POOL_DEP_MIN_GLASS = POOL_TUNING[3];
+// Scenes in LDS park twice as many at the least (scene1 1920x1080 x 256 frames: 13.95 -> 13.83 ms); trees in global
+// memory are better off with the smaller minima (1 M spheres at 3840x2160 x 64: 31.6 against 32.0 ms).
+constexpr uint32_t POOL_DEP_LDS_FACTOR = 2;
 
 // The direction-ordered records of a tree that stays in global memory (adopt_layout).
 __global__ void pt_order_nodes_kernel(const uint32_t* nodes64, uint32_t n, uint32_t* out) {
@@ -921,7 +924,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         // ---- lambertian / metal
         bool run_opaque = wants(w.cur == LANE_OPAQUE, PH_OPAQUE);
         if constexpr (XCHG) {
-            if (!run_opaque && may_park && waiting >= POOL_DEP_MIN_OPAQUE) {
+            if (!run_opaque && may_park && waiting >= POOL_DEP_MIN_OPAQUE * (LDS_SCENE ? POOL_DEP_LDS_FACTOR : 1u)) {
                 if (deposit(0u, w.cur == LANE_OPAQUE)) ran = true;
                 else run_opaque = true;  // the pool is full: the waves that empty it are behind
             }
@@ -943,7 +946,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
         // ---- glass
         bool run_glass = wants(w.cur == LANE_GLASS, PH_GLASS);
         if constexpr (XCHG) {
-            if (!run_glass && may_park && waiting >= POOL_DEP_MIN_GLASS) {
+            if (!run_glass && may_park && waiting >= POOL_DEP_MIN_GLASS * (LDS_SCENE ? POOL_DEP_LDS_FACTOR : 1u)) {
                 if (deposit(1u, w.cur == LANE_GLASS)) ran = true;
                 else run_glass = true;
             }
