@@ -276,7 +276,7 @@ int mi355pt_clear(mi355pt_ctx* c) {
     });
 }
 
-int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+static int render_queued(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds, bool wait_follows) {
     return guarded(c, [&]() -> int {
         if (!c) return MI355PT_ERR_ARG;
         if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "render: no scene (call set_scene)");
@@ -297,12 +297,17 @@ int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seed
         cfg.depth = c->settings.depth;
         cfg.glass_always_draws = !(c->desc.flags & MI355PT_FLAG_GLASS_SHORT_CIRCUIT);
         cfg.count = (c->desc.flags & MI355PT_FLAG_COUNT) != 0;
+        cfg.wait_follows = wait_follows;
         std::string err;
         if (!gpu::enqueue(c->dev, c->camera, cfg, seeds, n_frames, c->stats, err)) return fail(c, MI355PT_ERR_DEVICE, err);
         c->frames += (int32_t)n_frames;
         c->seed_index += n_frames;
         return MI355PT_OK;
     });
+}
+
+int mi355pt_render_async(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
+    return render_queued(c, n_frames, seeds, false);
 }
 
 int mi355pt_render_static(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
@@ -413,7 +418,7 @@ int mi355pt_wait(mi355pt_ctx* c) {
 }
 
 int mi355pt_render(mi355pt_ctx* c, uint32_t n_frames, const uint32_t* seeds) {
-    int r = mi355pt_render_async(c, n_frames, seeds);
+    int r = render_queued(c, n_frames, seeds, true);
     return r == MI355PT_OK ? mi355pt_wait(c) : r;
 }
 

@@ -38,6 +38,7 @@ struct RenderConfig {
     bool glass_always_draws = true;
     bool count = false;       // run the instrumented kernel variant (slower)
     uint32_t max_batch = 0;   // frames per launch; 0 = choose from the image size
+    bool wait_follows = false;  // the caller waits right after queueing (a blocking render): nothing can overlap the call's last launch
 };
 
 bool create(int device_id, void* stream, Device** out, std::string& err);

@@ -61,8 +61,9 @@ for rnd in range(int(os.environ.get("AB_ROUNDS", 5))):
         r.clear()
         r.render(F)
         s = r.stats()
-        res[name].append((s["render_ms"], s["rays"]))
+        res[name].append((s["render_ms"], s["rays"], s["resolve_ms"]))
 for name, xs in res.items():
     ms = sorted(x[0] for x in xs)
     rays = xs[0][1]
-    print(f"{name:28s} median {ms[len(ms)//2]:8.3f} ms  min {ms[0]:8.3f} ms  -> {rays/ms[len(ms)//2]/1e3:9.1f} Mrays/s (median)", flush=True)
+    acc = sorted(x[2] for x in xs)
+    print(f"{name:28s} median {ms[len(ms)//2]:8.3f} ms  min {ms[0]:8.3f} ms  -> {rays/ms[len(ms)//2]/1e3:9.1f} Mrays/s (median)  accumulation {acc[len(acc)//2]:6.3f} ms", flush=True)
