@@ -43,8 +43,10 @@ enum {
     MI355PT_BVH_SAH = 0,       /* library builds a binned-SAH tree (default).  Results equal MI355PT_BVH_REFERENCE's bit for
                                   bit except where the sphere test's cancellation lets a ray "hit" a sphere whose
                                   padded box it misses (far, tiny spheres; then the result depends on which boxes a
-                                  walk tests, in the reference as much as here): no pixel in the reference's scenes
-                                  or at 100 k spheres, <= 0.1 % of pixels at 1 M spheres (measured 0.04 %, horizon
+                                  walk tests, in the reference as much as here; also paths that travel ~1000 units,
+                                  e.g. inside a glass ground sphere): no pixel in the reference's scenes or at
+                                  100 k spheres, 1 texel in 900 renders of random scenes a quarter of which have a glass
+                                  ground sphere of radius 1000, <= 0.1 % of pixels at 1 M spheres (measured 0.04 %, horizon
                                   rows), <= 0.3 % at 10 M spheres (measured 0.23 %) */
     MI355PT_BVH_REFERENCE = 1, /* library builds the reference's own tree (bvh.rs:51-140, no child swap) and walks
                                   it the reference's way (compute.wgsl:85-96, 236-268: its box arithmetic, no
@@ -52,7 +54,9 @@ enum {
                                   tried, so results equal the reference's even for the rare rays whose computed
                                   root lies outside its sphere's box; several times slower than the default */
     MI355PT_BVH_LBVH = 2       /* tree built on the GPU (Morton order, leaves of one or two spheres): fastest set_scene,
-                                  more node visits per ray; exact ties in t resolve by sphere index */
+                                  more node visits per ray; same results as MI355PT_BVH_SAH (equal roots of two
+                                  spheres resolve by the reference's leaf order here too: it follows from the
+                                  spheres' order by z, one more sort on the device) */
 };
 
 enum {

@@ -446,6 +446,25 @@ int mi355pt_write_accum(mi355pt_ctx* c, const float* rgba, size_t n_floats, int3
     });
 }
 
+// Not part of the interface (no declaration in mi355pt.h): the tests read the packed scene back, so that a tree
+// built on the device can be checked node by node and walked by the CPU harness of the kernels' per-lane code.
+// `layout` receives the pt::SceneLayout (layout_bytes must be its size); *size the blob's; the blob is copied when
+// cap >= *size.
+extern "C" int mi355pt_debug_scene_blob(mi355pt_ctx* c, void* buf, size_t cap, size_t* size, void* layout, size_t layout_bytes) {
+    return guarded(c, [&]() -> int {
+        if (!c || !size || !layout || layout_bytes != sizeof(pt::SceneLayout)) return MI355PT_ERR_ARG;
+        if (!c->have_scene) return fail(c, MI355PT_ERR_STATE, "scene_blob: no scene (call set_scene)");
+        SETTLE_OR_RETURN(c);
+        std::string err;
+        pt::SceneLayout L;
+        size_t need = 0;
+        if (!gpu::read_scene_blob(c->dev, buf, cap, need, L, err)) return fail(c, MI355PT_ERR_DEVICE, err);
+        *size = need;
+        memcpy(layout, &L, sizeof L);
+        return MI355PT_OK;
+    });
+}
+
 int mi355pt_to_rgb8(mi355pt_ctx* c, int32_t frames, uint8_t* rgb, size_t n_bytes) {
     return guarded(c, [&]() -> int {
         if (!c || !rgb) return MI355PT_ERR_ARG;

@@ -78,6 +78,9 @@ bool set_alpha(Device* d, float alpha, std::string& err);
 bool debug_counters(Device* d, unsigned long long* out, size_t n, std::string& err);
 bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err);
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err);
+// The packed scene as the device holds it (tree included, whoever built it) and its layout; `need` = its size, copied
+// only when `out` holds that much.  For the tests: a tree built on the device is checked and walked on the CPU.
+bool read_scene_blob(Device* d, void* out, size_t cap, size_t& need, SceneLayout& layout, std::string& err);
 void* accum_device_ptr(Device* d);
 void* stream_handle(Device* d);
 bool synchronize(Device* d, std::string& err);

@@ -1584,6 +1584,20 @@ bool read_accum(Device* d, float* rgba, size_t n_floats, std::string& err) {
     return true;
 }
 
+bool read_scene_blob(Device* d, void* out, size_t cap, size_t& need, SceneLayout& layout, std::string& err) {
+    if (!d->have_scene) {
+        err = "scene_blob: no scene";
+        return false;
+    }
+    layout = d->layout;
+    need = d->layout.total_bytes;
+    if (!out || cap < need) return true;  // the caller asked for the size
+    DeviceGuard guard(d->id);
+    PT_SYNC_ALL(d);
+    PT_HIP(hipMemcpy(out, d->scene, need, hipMemcpyDeviceToHost));
+    return true;
+}
+
 bool write_accum(Device* d, const float* rgba, size_t n_floats, std::string& err) {
     if (n_floats != (size_t)d->n_pix * 4) {
         err = "write_accum: n_floats must be 4 * width * height";

@@ -241,14 +241,31 @@ __global__ void lbvh_emit(const Sphere32* spheres, const uint32_t* order, int n,
     out[new_id[i]] = nd;
 }
 
-// Spheres and their material words in leaf (= sorted) order; the tie rank is the sphere's index.
-__global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, uint32_t n, f4* out_spheres, u2* out_info) {
+// Tie ranks: where the reference's own tree would have each sphere among its leaves (reference_leaf_rank), so that
+// two spheres with bit-identical roots resolve as in the reference's walk.  That needs the spheres' order by z --
+// one stable 32-bit sort -- and nothing of the reference tree itself.
+__global__ void lbvh_z_keys(const Sphere32* s, uint32_t n, uint32_t* keys, uint32_t* vals) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = __float_as_uint(s[i].pos[2] + 0.0f);  // -0 sorts with +0, as it compares
+    keys[i] = (b & 0x80000000u) ? ~b : b | 0x80000000u;      // unsigned order = float order
+    vals[i] = i;
+}
+__global__ void lbvh_tie_ranks(const uint32_t* by_z, uint32_t n, uint32_t* tie_rank) {
+    const uint32_t p = blockIdx.x * BLK + threadIdx.x;
+    if (p >= n) return;
+    tie_rank[n < 4u ? p : by_z[p]] = reference_leaf_rank(n, p);  // fewer than four spheres: the reference sorts nothing
+}
+
+// Spheres and their material words in leaf (= sorted) order.
+__global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, const uint32_t* tie_rank, uint32_t n, f4* out_spheres,
+                            u2* out_info) {
     const uint32_t p = blockIdx.x * BLK + threadIdx.x;
     if (p >= n) return;
     const Sphere32 s = spheres[order[p]];
     out_spheres[p] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad * s.rad};
     const uint32_t type = s.mat_type > 3u ? 4u : s.mat_type;
-    out_info[p] = u2{type | (s.mat_index << 3), order[p]};
+    out_info[p] = u2{type | (s.mat_index << 3), tie_rank[order[p]]};
 }
 
 struct Scratch {  // device allocations of one build, released on every exit path
@@ -293,8 +310,8 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         err = "lbvh: out of device memory";
         return false;
     }
-    uint32_t *area_keys, *area_keys_sorted, *area_vals, *by_area, *below, *below_before, *new_id;
-    if (!tmp.get(&area_keys, n) || !tmp.get(&area_keys_sorted, n) || !tmp.get(&area_vals, n) || !tmp.get(&by_area, n) ||
+    uint32_t *area_keys, *area_keys_sorted, *area_vals, *by_area, *below, *below_before, *new_id, *tie_rank;
+    if (!tmp.get(&tie_rank, n) || !tmp.get(&area_keys, n) || !tmp.get(&area_keys_sorted, n) || !tmp.get(&area_vals, n) || !tmp.get(&by_area, n) ||
         !tmp.get(&below, n) || !tmp.get(&below_before, n) || !tmp.get(&new_id, n)) {
         err = "lbvh: out of device memory";
         return false;
@@ -302,7 +319,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     const uint32_t n_nodes = n - 1u;
     size_t sort_bytes = 0, sort32_bytes = 0, scan_bytes = 0;
     PT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
-    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_nodes, 0, 32, st));
+    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n, 0, 32, st));
     PT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, below, below_before, 0u, n_nodes, rocprim::plus<uint32_t>(), st));
     sort_bytes = std::max(sort_bytes, std::max(sort32_bytes, scan_bytes));
     char* sort_tmp;
@@ -319,6 +336,12 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     PT_HIP(hipMemsetAsync(max_depth, 0, sizeof(int), st));
     PT_HIP(hipMemsetAsync(kept_count, 0, sizeof(int), st));
     const dim3 grid((n + BLK - 1) / BLK), block(BLK);
+    // tie ranks first: the sort borrows the buffers of the later sort by box area
+    hipLaunchKernelGGL(lbvh_z_keys, grid, block, 0, st, spheres, n, area_keys, area_vals);
+    PT_HIP(hipGetLastError());
+    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, area_keys, area_keys_sorted, area_vals, by_area, n, 0, 32, st));
+    hipLaunchKernelGGL(lbvh_tie_ranks, grid, block, 0, st, by_area, n, tie_rank);
+    PT_HIP(hipGetLastError());
     hipLaunchKernelGGL(lbvh_bounds, grid, block, 0, st, spheres, n, box);
     hipLaunchKernelGGL(lbvh_codes, grid, block, 0, st, spheres, n, box, keys, vals);
     PT_HIP(hipGetLastError());
@@ -360,7 +383,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     hipLaunchKernelGGL(lbvh_new_ids, grid, block, 0, st, by_area, below, below_before, (int)n_nodes, (int)top, new_id);
     hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box, new_id,
                        first_of, count_of, leaf_max, reinterpret_cast<Node64*>(d->scene + L.off_nodes));
-    hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
+    hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, tie_rank, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
                        reinterpret_cast<u2*>(d->scene + L.off_info));
     PT_HIP(hipGetLastError());
     if (a.n_lights) PT_HIP(hipMemcpyAsync(d->scene + L.off_lights, a.lights, a.n_lights * 16, hipMemcpyHostToDevice, st));

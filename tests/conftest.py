@@ -118,7 +118,37 @@ def emul():
         return out, order
 
     L.tile_lists = tile_lists
+    L.emul_set_blob.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+
+    def set_blob(blob=None, layout=None):
+        """Walk this packed scene (device_scene_blob) in render() instead of the harness's own packing; None: back."""
+        if blob is None:
+            return L.emul_set_blob(None, 0, None, 0)
+        r = L.emul_set_blob(blob.ctypes.data, blob.nbytes, layout.ctypes.data, layout.nbytes)
+        if r != 0:
+            raise RuntimeError("emul_set_blob: layout and blob do not match")
+
+    L.set_blob = set_blob
     return L
+
+
+SCENE_LAYOUT_BYTES = 80   # sizeof(pt::SceneLayout) (pt_types.h); the library and the harness both check it
+
+
+def device_scene_blob(renderer):
+    """(blob, layout) of the packed scene a Renderer's device holds, tree included, whoever built it: the library's
+    test-only export mi355pt_debug_scene_blob."""
+    import ctypes as C
+    from pathtracer_amd import binding
+    L = C.CDLL(binding.library_path())
+    fn = L.mi355pt_debug_scene_blob
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+    layout = np.zeros(SCENE_LAYOUT_BYTES, np.uint8)
+    size = C.c_size_t(0)
+    assert fn(renderer._ctx, None, 0, C.byref(size), layout.ctypes.data, layout.nbytes) == 0
+    blob = np.zeros(size.value, np.uint8)
+    assert fn(renderer._ctx, blob.ctypes.data, blob.nbytes, C.byref(size), layout.ctypes.data, layout.nbytes) == 0
+    return blob, layout
 
 
 def oracle_scene(orc, scene, **kw):

@@ -28,11 +28,78 @@ int g_tile_lists = 1;         // camera rays test their tile's candidate list (t
 uint32_t g_tile_list_max = TILE_LIST_CAP;
 uint64_t g_list_rays = 0, g_list_tests = 0, g_walk_tiles = 0, g_list_tiles = 0;
 bool g_log = true;
+const bool g_trace = getenv("PT_EMUL_TRACE") != nullptr;  // every ray of every path to stderr (debugging aid)
+std::vector<char> g_blob;   // a packed scene read back from the device (emul_set_blob): rendered instead of the harness's own packing
+SceneLayout g_blob_layout;
 }  // namespace
 
 extern "C" {
 
 const char* emul_error() { return g_err.c_str(); }
+// A packed scene as the device holds it (tree included) and its layout: emul_render then walks that one, whatever
+// arrays it is given (n = 0: back to the harness's own packing).  Lets a tree built on the GPU be walked on the CPU.
+int emul_set_blob(const void* blob, size_t n, const void* layout, size_t layout_bytes) {
+    g_blob.clear();
+    if (n == 0) return 0;
+    if (layout_bytes != sizeof(SceneLayout)) return -1;
+    memcpy(&g_blob_layout, layout, sizeof g_blob_layout);
+    if (g_blob_layout.total_bytes != n) return -1;
+    g_blob.assign((const char*)blob, (const char*)blob + n);
+    return 0;
+}
+// Structure of the tree in the blob set by emul_set_blob: every interior node reached exactly once from node 0, every
+// sphere in exactly one leaf, every child box inside its parent's box for it, every sphere's padded box
+// (bounding_box.rs:17-27; the radius is the root of the stored square, hence the small tolerance) inside its leaf's
+// box, no chain of interior nodes longer than the layout says (it sizes the traversal stack).  0 = sound; a positive code names the failed check.
+int emul_check_blob_tree() {
+    if (g_blob.empty()) return -1;
+    const SceneLayout& L = g_blob_layout;
+    if (L.node_half) return -2;
+    const Node64* nodes = reinterpret_cast<const Node64*>(g_blob.data() + L.off_nodes);
+    const f4* spheres = reinterpret_cast<const f4*>(g_blob.data() + L.off_spheres);
+    std::vector<uint8_t> seen_node(L.n_nodes, 0), seen_sphere(L.n_spheres, 0);
+    struct Todo { int32_t link; uint32_t depth; float lo[3], hi[3]; };
+    std::vector<Todo> todo;
+    auto child_box = [&](const Node64& nd, int k, float* lo, float* hi) {
+        const float* q = reinterpret_cast<const float*>(&nd);
+        for (int a = 0; a < 3; a++) lo[a] = q[k * 6 + a], hi[a] = q[k * 6 + 3 + a];
+    };
+    Todo root{0, 1u, {-INFINITY, -INFINITY, -INFINITY}, {INFINITY, INFINITY, INFINITY}};
+    todo.push_back(root);
+    uint32_t deepest = 0;
+    while (!todo.empty()) {
+        const Todo t = todo.back();
+        todo.pop_back();
+        if (t.link >= 0) {
+            if ((uint32_t)t.link >= L.n_nodes || seen_node[t.link]++) return 3;
+            deepest = std::max(deepest, t.depth);
+            const Node64& nd = nodes[t.link];
+            const int32_t c[2] = {nd.child0, nd.child1};
+            for (int k = 0; k < 2; k++) {
+                Todo n{c[k], t.depth + 1u, {0, 0, 0}, {0, 0, 0}};
+                child_box(nd, k, n.lo, n.hi);
+                for (int a = 0; a < 3; a++)
+                    if (!(n.lo[a] >= t.lo[a] && n.hi[a] <= t.hi[a] && n.lo[a] <= n.hi[a])) return 4;
+                todo.push_back(n);
+            }
+        } else {
+            const uint32_t ref = ~(uint32_t)t.link, first = ref & LEAF_FIRST_MASK, count = (ref >> LEAF_COUNT_SHIFT) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                if (first + k >= L.n_spheres || seen_sphere[first + k]++) return 6;
+                const f4 s = spheres[first + k];
+                const float r = sqrtf(s.w), c[3] = {s.x, s.y, s.z};
+                for (int a = 0; a < 3; a++) {
+                    const float tol = 4e-7f * (fabsf(c[a]) + r + 0.01f);
+                    if (!((c[a] - r) - 0.01f >= t.lo[a] - tol && (c[a] + r) + 0.01f <= t.hi[a] + tol)) return 5;
+                }
+            }
+        }
+    }
+    for (uint8_t v : seen_node) if (v != 1) return 7;
+    for (uint8_t v : seen_sphere) if (v != 1) return 8;
+    if (deepest > L.max_depth) return 9;
+    return 0;
+}
 // 1: closest hits are found by testing every sphere (no tree, no boxes); 2: the same with each sphere's own
 // padded box as the only cull, logging every root that box would hide
 void emul_set_brute_force(int mode) { g_brute_force = mode; }
@@ -57,7 +124,11 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     std::vector<char> blob;
     SceneLayout L;
     Bvh2 bvh;
-    if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) return -1;
+    if (!g_blob.empty()) {
+        blob = g_blob, L = g_blob_layout;
+    } else if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) {
+        return -1;
+    }
     if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes, bvh_info[3] = L.node_half;
     PtrMem mem{blob.data()};
     // A float-node scene that the device would stage in LDS is walked there through direction-ordered
@@ -150,7 +221,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                             Walk w;
                             walk_begin<false>(w, L, ps.o, ps.d);
                             for (uint32_t si = 0; si < L.n_spheres; si++) {
-                                if (g_brute_force == 2) {  // with every sphere's own padded box as the only cull
+                                if (g_brute_force == 2 && g_blob.empty()) {  // with every sphere's own padded box as the only cull
                                     f4 sp = mem.load<f4>(L.off_spheres + si * 16u);
                                     sp.w = a.spheres[bvh.order[si]].rad;  // the blob holds rad * rad
                                     float tn;
@@ -175,6 +246,9 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
                         else if (L.node_half) closest_hit<PtrMem, HostStack, true, true>(mem, L, st, ps.o, ps.d, hit, cnt);
                         else closest_hit<PtrMem, HostStack, true, false>(mem, L, st, ps.o, ps.d, hit, cnt);
                         big[0] += cnt.nodes, big[1] += cnt.tests, big[2] += cnt.accepted, big[8]++;
+                        if (g_trace)
+                            fprintf(stderr, "pixel %u,%u frame %u sample %d bounce %d: o=(%.9g %.9g %.9g) d=(%.9g %.9g %.9g) t=%.9g sphere(leaf order)=%d back=%d\n", x, y,
+                                    f, s, ps.bounce, ps.o.x, ps.o.y, ps.o.z, ps.d.x, ps.d.y, ps.d.z, hit.t, hit.idx, (int)hit.back);
                         V3 radiance;
                         uint32_t mat;
                         bool done = scatter(mem, L, hit, ps, depth, glass_always_draws != 0, radiance, mat);
@@ -275,6 +349,7 @@ int emul_tile_lists(const void* spheres32, size_t n_spheres, const void* lights,
     return 0;
 }
 
+uint32_t emul_reference_leaf_rank(uint32_t n, uint32_t pos) { return reference_leaf_rank(n, pos); }
 uint32_t emul_pixel_hash(uint32_t px, uint32_t py, uint32_t w, uint32_t h) { return pixel_hash(px, py, w, h); }
 float emul_det_sin(float x) { return det_sin(x); }
 

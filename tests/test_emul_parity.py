@@ -329,3 +329,31 @@ def test_candidate_lists_hold_every_sphere_a_camera_ray_hits(emul, pa, orc):
             if hit[y, x] >= 0:
                 rec = lists[y // 8, x // 8]
                 assert hit[y, x] in set(order[rec[1:1 + rec[0]]].tolist()), (x, y)
+
+
+def test_tie_rank_formula_equals_the_reference_tree(emul, pa):
+    # A tree built on the GPU takes its tie ranks (which of two spheres with bit-identical roots wins,
+    # compute.wgsl:129) from a sort by z and reference_leaf_rank(n, position) instead of building the reference's
+    # tree; the formula must give every sphere the place the reference's own tree (bvh.rs:51-140, no child swap)
+    # gives it among its leaves.
+    emul.emul_reference_leaf_rank.restype = __import__("ctypes").c_uint32
+    rng = np.random.default_rng(5)
+    for n in list(range(2, 40)) + [63, 64, 65, 100, 257, 1000]:
+        sp = np.zeros(n, pa.renderer.SPHERE_DT)
+        sp["pos"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+        if n > 6:   # equal keys keep their order (stable sort); -0 equals +0
+            sp["pos"][3, 2] = sp["pos"][1, 2]
+            sp["pos"][5, 2] = np.float32(-0.0)
+            sp["pos"][2, 2] = np.float32(0.0)
+            sp["pos"][6, 2] = np.float32(-0.0)
+        sp["rad"] = 0.3
+        nodes = pa.bvh_build_reference(sp, 0, 1)
+        leaves = [int(nd["index"]) for nd in nodes if nd["type"] == 1]
+        assert sorted(leaves) == list(range(n))
+        by_z = np.argsort(sp["pos"][:, 2], kind="stable") if n >= 4 else np.arange(n)
+        got = np.zeros(n, np.int64)
+        for pos, sphere in enumerate(by_z):
+            got[sphere] = emul.emul_reference_leaf_rank(n, pos)
+        want = np.zeros(n, np.int64)
+        want[leaves] = np.arange(n)
+        assert (got == want).all(), n

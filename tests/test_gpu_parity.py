@@ -323,13 +323,13 @@ def test_queued_renders_equal_blocking_renders(pa, monkeypatch):
 @pytest.mark.parametrize("block", range(4))
 def test_random_scenes(pa, orc, block):
     # 10 random scenes per case (overlaps, nesting, duplicates, camera inside spheres, odd glass, unknown
-    # materials) x the three trees; the tree built on the GPU orders equal roots by sphere index, so it
-    # gets the same scenes without exact duplicates
+    # materials) x the three trees (equal roots resolve by the reference's leaf order in all three); the tree
+    # built on the GPU also gets the same scenes without exact duplicates
     for k in range(10):
         seed = 5000 + 10 * block + k
         W, H = 64, 40
         samples, depth = (1, 50) if k % 3 else (3, 5)
-        for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE)), (False, (pa.BVH_LBVH,))):
+        for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE, pa.BVH_LBVH)), (False, (pa.BVH_LBVH,))):
             sc = random_scene(pa, seed, duplicates=dup)
             osc = oracle_scene(orc, sc)
             ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS[:3], samples=samples, depth=depth, threads=16)
@@ -381,7 +381,7 @@ def test_tree_built_on_the_gpu(pa, orc, name):
 
 
 def test_tree_built_on_the_gpu_edge_cases(pa, orc):
-    # two spheres (one interior node); many spheres at one position (equal Morton codes, ties by index);
+    # two spheres (one interior node); many spheres at one position (equal Morton codes);
     # the default scene (4 spheres, one of them the 1000-radius ground)
     W, H = 64, 48
     two = pa.Scene.default()
@@ -398,6 +398,43 @@ def test_tree_built_on_the_gpu_edge_cases(pa, orc):
         acc, gs = gpu_render(pa, sc, W, H, SEEDS[:3], bvh_mode=pa.BVH_LBVH)
         assert bits_equal(ref, acc) and gs["rays"] == st["rays"]
         assert 1 <= gs["bvh_nodes"] <= len(sc.spheres) - 1   # subtrees of two spheres are folded into leaves
+
+
+def test_tree_built_on_the_gpu_is_sound_and_breaks_ties_like_the_reference(pa, orc, emul):
+    # The packed scene is read back from the device: the tree must be a tree (every sphere in one leaf, every box
+    # inside its parent's, every sphere's padded box inside its leaf's), the CPU harness walking that very tree must
+    # give the GPU's bits, and where two different spheres have bit-identical roots the winner must be the
+    # reference's (compute.wgsl:129: the later leaf of the reference's own tree) -- the tie ranks come from a sort
+    # by z on the device, not from the reference's tree.  Scene 50264 of tools/soak.py at 96 x 64 has such a tie
+    # between two overlapping glass spheres in texel (47, 27), frame seed 1558188.
+    from conftest import device_scene_blob
+    sc = random_scene(pa, 50264, duplicates=False)
+    osc = oracle_scene(orc, sc)
+    W, H, seeds = 96, 64, [1558188, 50264]
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, seeds, samples=2, depth=7, threads=16)
+    with pa.Renderer(sc, pa.Settings(2, 7), W, H, bvh_mode=pa.BVH_LBVH) as r:
+        r.render(seeds=seeds)
+        acc = r.read_accum()
+        blob, layout = device_scene_blob(r)
+    assert bits_equal(ref, acc)
+    emul.set_blob(blob, layout)
+    try:
+        assert emul.emul_check_blob_tree() == 0
+        crop = (40, 56, 24, 32)
+        x0, x1, y0, y1 = crop
+        walked, _, _ = emul.render(sc, osc.camera(W, H), W, H, seeds, samples=2, depth=7, crop=crop)
+        assert bits_equal(walked[y0:y1, x0:x1], acc[y0:y1, x0:x1])
+    finally:
+        emul.set_blob(None)
+    for n in (3000, 100_000):   # a larger tree: soundness only
+        from pathtracer_amd import synth
+        with pa.Renderer(synth.plane_scene(n), pa.Settings(1, 50), 64, 36, bvh_mode=pa.BVH_LBVH) as r:
+            blob, layout = device_scene_blob(r)
+        emul.set_blob(blob, layout)
+        try:
+            assert emul.emul_check_blob_tree() == 0
+        finally:
+            emul.set_blob(None)
 
 
 def test_tree_built_on_the_gpu_large(pa, orc):

@@ -1,7 +1,10 @@
 """Development soak: random scenes (tests/conftest.py) x three trees on the GPU against the oracle.
 usage: python tools/soak.py <count> [<first seed>]
 SOAK_FRAMES=n (default 2): frames per render; with n >= 10 the first 9 go in one call (which measures the tile order)
-and the rest in a second one, so that the sky-tile split of the accumulation kernel is exercised too."""
+and the rest in a second one, so that the sky-tile split of the accumulation kernel is exercised too;
+SOAK_QUEUE=1: the rest is queued two frames per call without waiting, so that launches add their predecessor's
+results (with MI355PT_XCHG=1 MI355PT_BLOCK=1024, which force the kernel instance that does that at this size);
+SOAK_W, SOAK_H: image size (default 48 x 32)."""
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import numpy as np
@@ -12,9 +15,9 @@ orc.build()
 bad = 0
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 for seed in range(start, start + int(sys.argv[1])):
-    W, H = 48, 32
+    W, H = int(os.environ.get("SOAK_W", 48)), int(os.environ.get("SOAK_H", 32))
     samples, depth = (1, 50) if seed % 4 else (2, 7)
-    for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE)), (False, (pa.BVH_LBVH,))):
+    for dup, modes in ((True, (pa.BVH_SAH, pa.BVH_REFERENCE, pa.BVH_LBVH)), (False, (pa.BVH_LBVH,))):
         sc = random_scene(pa, seed, duplicates=dup)
         osc = oracle_scene(orc, sc)
         nf = int(os.environ.get("SOAK_FRAMES", 2))
@@ -24,7 +27,11 @@ for seed in range(start, start + int(sys.argv[1])):
             with pa.Renderer(sc, pa.Settings(samples, depth), W, H, bvh_mode=mode) as r:
                 if nf >= 10:
                     r.render(seeds=seeds[:9])
-                    r.render(seeds=seeds[9:])
+                    if os.environ.get("SOAK_QUEUE") == "1":
+                        for k in range(9, nf, 2):
+                            r.render(seeds=seeds[k:k + 2], wait=False)
+                    else:
+                        r.render(seeds=seeds[9:])
                 else:
                     r.render(seeds=seeds)
                 if not bits_equal(ref, r.read_accum()) or r.stats()["rays"] != st["rays"]:
