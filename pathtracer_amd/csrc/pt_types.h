@@ -100,6 +100,30 @@ struct SceneLayout {
     uint32_t max_depth;               // deepest interior-node chain; bounds the traversal stack
 };
 
+#if defined(__HIPCC__)
+#define PT_TYPES_FN __host__ __device__ inline
+#else
+#define PT_TYPES_FN inline
+#endif
+// Position, among the leaves of the reference's tree in the order its walk reaches them (bvh.rs:51-140 without child
+// swaps, flattened left first: compute.wgsl:236-268 visits leaves in that order and a later leaf replaces an equal
+// t, :129), of the sphere at position p of the n spheres sorted by z.  The reference sorts every range by z
+// (bvh.rs:82-96: the axis choice compares sentinel extents, so it is always z) with a stable sort, which leaves a
+// sorted range as it is: the tree's shape, and so this position, depends on n and p alone.  Ranges of two keep their
+// order, of three put their last element first (bvh.rs:63-80), longer ones split at n / 2.  Scenes of fewer than four
+// spheres are never sorted: p is then the sphere's index.
+PT_TYPES_FN uint32_t reference_leaf_rank(uint32_t n, uint32_t p) {
+    uint32_t lo = 0u, hi = n, base = 0u;
+    for (;;) {
+        const uint32_t m = hi - lo;
+        if (m <= 2u) return base + (p - lo);
+        if (m == 3u) return p == hi - 1u ? base : base + 1u + (p - lo);
+        const uint32_t mid = lo + m / 2u;
+        if (p < mid) hi = mid;
+        else base += mid - lo, lo = mid;
+    }
+}
+
 // A scene whose blob plus the traversal stacks of a 256-lane workgroup stays within this budget is
 // staged in LDS by every workgroup (two or more workgroups per CU still fit).
 constexpr uint32_t LDS_SCENE_LIMIT = 64u * 1024u;

@@ -135,6 +135,32 @@ SceneLayout make_layout(const SceneArrays& a, uint32_t n_nodes, bool half_nodes)
     return L;
 }
 
+// Tie ranks without the reference's tree: the spheres' stable order by z (three 11-bit passes of a radix sort over
+// keys that order like the floats, -0 with +0) and reference_leaf_rank.
+static void tie_ranks_by_z(const Sphere32* spheres, uint32_t n, std::vector<uint32_t>& rank) {
+    rank.resize(n);
+    if (n < 4u) {  // the reference sorts nothing below four spheres
+        for (uint32_t i = 0; i < n; i++) rank[i] = reference_leaf_rank(n, i);
+        return;
+    }
+    std::vector<uint64_t> a(n), b(n);  // key << 32 | sphere index
+    for (uint32_t i = 0; i < n; i++) {
+        const float z = spheres[i].pos[2] + 0.0f;
+        uint32_t bits;
+        memcpy(&bits, &z, 4);
+        const uint32_t key = (bits & 0x80000000u) ? ~bits : bits | 0x80000000u;
+        a[i] = (uint64_t)key << 32 | i;
+    }
+    for (int shift = 32; shift < 64; shift += 11) {
+        size_t count[2049] = {0};
+        for (uint32_t i = 0; i < n; i++) count[((a[i] >> shift) & 2047u) + 1u]++;
+        for (int k = 0; k < 2048; k++) count[k + 1] += count[k];
+        for (uint32_t i = 0; i < n; i++) b[count[(a[i] >> shift) & 2047u]++] = a[i];
+        a.swap(b);
+    }
+    for (uint32_t p = 0; p < n; p++) rank[(uint32_t)a[p]] = reference_leaf_rank(n, p);
+}
+
 bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref_nodes, size_t n_ref_nodes,
                 std::vector<char>& blob, SceneLayout& L, Bvh2& bvh, std::string& err) {
     if (!validate_scene(a, err)) return false;
@@ -142,11 +168,11 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
     std::vector<uint32_t> rank;
     std::vector<Node48> own_ref;
     Bvh2 from_ref;
-    // Tie ranks come from the reference-order walk.  Above this size the reference tree is not built
-    // just for ranks: two spheres with bit-identical roots then resolve by sphere index.
-    const uint32_t kRankLimit = 4u << 20;
+    // Tie ranks -- which of two spheres with bit-identical roots wins -- are the spheres' places among the leaves of
+    // the reference's tree: read off that tree when it is walked (a caller's, or the library's own copy of it), else
+    // worked out from the spheres' order by z, which is all that tree's shape depends on.
     const bool caller_tree = ref_nodes != nullptr;
-    if (!caller_tree && (reference_topology || n <= kRankLimit)) {
+    if (!caller_tree && reference_topology) {
         if (!build_reference(a.spheres, n, 0, 1, own_ref, err)) return false;
         ref_nodes = own_ref.data();
         n_ref_nodes = own_ref.size();
@@ -155,8 +181,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
         if (n_ref_nodes > 0xffffffffull || !from_reference(ref_nodes, (uint32_t)n_ref_nodes, n, from_ref, rank, err))
             return false;
     } else {
-        rank.resize(n);
-        for (uint32_t i = 0; i < n; i++) rank[i] = i;
+        tie_ranks_by_z(a.spheres, n, rank);
     }
     if (caller_tree || reference_topology) {
         bvh = std::move(from_ref);
