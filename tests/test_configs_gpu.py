@@ -28,6 +28,30 @@ def test_c1_scene1_400x225x16_whole_image(pa, orc):
             assert bits_equal(ref, r.read_accum()) and r.stats()["rays"] == st["rays"] and r.samples() == 16
 
 
+def test_c2_scene1_1080p_1024_frames_whole_image(pa, orc):
+    # The headline configuration at its stated size (offline.rs:15-16,34: 1920x1080 here, 1024 frames of one sample).
+    # The oracle needs minutes for it, the reference-walk mode -- bit-equal to the oracle wherever both have been
+    # run, and exactly the reference's sphere tests -- a second: every texel of the default tree's image must equal
+    # the reference walk's, the ray counts too, and a 64x32 crop over the three large spheres equals the oracle.
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    W, H, F = 1920, 1080, 1024
+    out = {}
+    for mode in (pa.BVH_SAH, pa.BVH_REFERENCE):
+        with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=mode) as r:
+            r.render(F)
+            out[mode] = (r.read_accum(), r.stats())
+            assert r.samples() == F
+    a, sa = out[pa.BVH_SAH]
+    b, sb = out[pa.BVH_REFERENCE]
+    assert bits_equal(a, b)
+    assert sa["rays"] == sb["rays"] and sa["paths"] == sb["paths"] == W * H * F
+    x0, x1, y0, y1 = crop = (928, 992, 560, 592)
+    ref, _ = orc.render(osc, osc.camera(W, H), W, H, seeds_of(pa, F), crop=crop, threads=16)
+    assert bits_equal(ref[y0:y1, x0:x1], a[y0:y1, x0:x1])
+    assert np.unique(a[y0:y1, x0:x1, 0]).size > 300           # the crop is a real image
+
+
 def full_size_properties(pa, orc, sc, W, H, frames, crop, exact=True):
     seeds = seeds_of(pa, frames)
     with pa.Renderer(sc, pa.Settings(1, 50), W, H) as r:
