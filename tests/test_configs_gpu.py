@@ -188,6 +188,40 @@ def test_reduce_over_contexts(pa):
             r.close()
 
 
+_scene_cache = {}
+
+
+def plane(n):
+    from pathtracer_amd import synth
+    if n not in _scene_cache:
+        _scene_cache[n] = synth.plane_scene(n)
+    return _scene_cache[n]
+
+
+def test_c5_one_rank_share_of_16384_frames(pa):
+    # C5 at its stated length, as one of its eight ranks sees it: the 10 M-sphere scene at 3840x2160 and the 2 048
+    # frames mi355pt_partition_frames gives rank 3 of 8 out of 16 384 (frames 6 144 .. 8 191 of the schedule) -- 32
+    # launches of 64 frames, so the queue, the seed ring, the two result buffers and the refresh of the tile order
+    # run as long as they do in the configuration.  Once as one blocking call, once as four queued calls: same bits,
+    # same counts.  (What no one-GPU box can add is the reduce between the eight ranks.)
+    W, H, total, ranks, rank = 3840, 2160, 16384, 8, 3
+    first, count = pa.partition_frames(total, ranks, rank)
+    assert (first, count) == (6144, 2048)
+    seeds = seeds_of(pa, count, first)
+    with pa.Renderer(plane(10_000_000), pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) as r:
+        r.render(seeds=seeds)
+        a, sa = r.read_accum(), r.stats()
+        assert r.samples() == count
+        r.clear()
+        for k in range(4):
+            r.render(seeds=seeds[k * 512:(k + 1) * 512], wait=False)
+        b, sb = r.read_accum(), r.stats()
+    assert bits_equal(a, b)
+    assert sa["launches"] >= 32 and sa["paths"] == sb["paths"] == W * H * count and sa["rays"] == sb["rays"]
+    assert np.all(a[..., 3] == 1.0) and np.isfinite(a).all() and a[..., :3].min() >= 0.0
+    assert a[..., :3].max() <= 1.0001 * count       # the generator's one light is (1, 1, 1), the sky at most that
+
+
 def test_c5_ten_million_spheres_partitioned_over_eight_contexts(pa):
     # C5 in miniature: the 10 M-sphere scene at 4K, its frames split eight ways by mi355pt_partition_frames
     # (the eight contexts share this box's one device; on an eight-GPU node each would have its own and the sum
@@ -196,8 +230,7 @@ def test_c5_ten_million_spheres_partitioned_over_eight_contexts(pa):
     # context that renders every frame only the order of the 256 float additions per texel differs (root mean
     # square 1e-6 relative; a single texel at most 2e-5, i.e. 256 roundings one way).  Trees built on the device:
     # eight host builds of this scene would take a quarter of a minute.
-    from pathtracer_amd import synth
-    sc = synth.plane_scene(10_000_000)
+    sc = plane(10_000_000)
     W, H, F, N = 3840, 2160, 256, 8      # 32 frames per context: the tile order is measured inside the partitioned path
     with pa.Renderer(sc, pa.Settings(1, 50), W, H, bvh_mode=pa.BVH_LBVH) as r:
         r.render(F)
