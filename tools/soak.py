@@ -12,7 +12,7 @@ import pathtracer_amd as pa
 from oracle import orc
 from conftest import random_scene, oracle_scene, bits_equal
 orc.build()
-bad = 0
+bad = unexplained = 0
 start = int(sys.argv[2]) if len(sys.argv) > 2 else 20000
 for seed in range(start, start + int(sys.argv[1])):
     W, H = int(os.environ.get("SOAK_W", 48)), int(os.environ.get("SOAK_H", 32))
@@ -36,5 +36,9 @@ for seed in range(start, start + int(sys.argv[1])):
                     r.render(seeds=seeds)
                 if not bits_equal(ref, r.read_accum()) or r.stats()["rays"] != st["rays"]:
                     bad += 1
-                    print("MISMATCH seed", seed, "mode", mode, flush=True)
-print("done, mismatches:", bad)
+                    # paths that cross a thousand units of glass come back at the small spheres with roots no padded
+                    # box contains: what is hit then depends on the boxes a walk tests, in the reference as here
+                    known = bool(((sc.spheres["rad"] >= 100) & (sc.spheres["mat_type"] == 3)).any()) and mode != pa.BVH_REFERENCE
+                    unexplained += 0 if known else 1
+                    print("MISMATCH seed", seed, "mode", mode, "(glass sphere of radius >= 100: tree-dependent class)" if known else "UNEXPLAINED", flush=True)
+print("done, mismatches:", bad, "unexplained:", unexplained)
