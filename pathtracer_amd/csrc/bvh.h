@@ -17,6 +17,7 @@ struct Bvh2 {
     std::vector<Node64> nodes;    // node 0 is the root; always interior (a scene has >= 2 spheres)
     std::vector<uint32_t> order;  // leaf-ordered sphere ids: leaf (first,count) indexes this array
     uint32_t max_depth = 0;       // interior nodes on the longest root-to-leaf chain
+    uint32_t n_hoisted = 0;       // 1: order.back() is in no leaf (SceneLayout::n_hoisted)
 };
 
 // Renumbers the interior nodes: the first min(k_top, n) indices go to the nodes with the largest

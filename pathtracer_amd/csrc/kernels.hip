@@ -939,6 +939,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     finish_sample(radiance);
                 } else {
                     walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
+                    if constexpr (SCENE != SCENE_REFERENCE) walk_test_hoisted<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, cnt);
                     if constexpr (FAST) lane_rays++; else rays++;
                 }
             }
@@ -961,6 +962,7 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                     finish_sample(radiance);
                 } else {
                     walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
+                    if constexpr (SCENE != SCENE_REFERENCE) walk_test_hoisted<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, cnt);
                     if constexpr (FAST) lane_rays++; else rays++;
                 }
             }
@@ -1098,7 +1100,10 @@ __global__ void __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(BLK ==
                         }
                     }
                 }
-                if (walks) walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
+                if (walks) {
+                    walk_begin<HALF>(w, P.L, ps.o, ps.d, mem.root());
+                    if constexpr (SCENE != SCENE_REFERENCE) walk_test_hoisted<Mem, COUNT>(mem, P.L, w, ps.o, ps.d, cnt);
+                }
             }
         }
         if (!ran) {

@@ -502,6 +502,12 @@ PT_FN void walk_test_sphere(const Mem& mem, const SceneLayout& L, Walk& w, V3 o,
     }
 }
 
+// The sphere that is kept out of the tree (SceneLayout::n_hoisted), tested where a walk begins.
+template <class Mem, bool COUNT>
+PT_FN void walk_test_hoisted(const Mem& mem, const SceneLayout& L, Walk& w, V3 o, V3 d, Counters& cnt) {
+    if (L.n_hoisted) walk_test_sphere<Mem, COUNT>(mem, L, w, o, d, L.n_spheres - 1u, cnt);
+}
+
 // Every sphere of the current leaf, then the next stack entry.  Requires a leaf.
 template <class Mem, class Stack, bool COUNT>
 PT_FN void walk_leaf(const Mem& mem, const SceneLayout& L, Stack& stack, Walk& w, V3 o, V3 d, Counters& cnt) {
@@ -532,6 +538,7 @@ PT_FN void closest_hit(const Mem& mem, const SceneLayout& L, Stack& stack, V3 o,
                        Counters& cnt) {
     Walk w;
     walk_begin<HALF>(w, L, o, d, mem.root());
+    if constexpr (!REFERENCE_WALK) walk_test_hoisted<Mem, COUNT>(mem, L, w, o, d, cnt);
     for (;;) {
         while (walk_is_node(w.cur)) {
             if constexpr (REFERENCE_WALK) walk_node_reference<Mem, Stack, COUNT>(mem, L, stack, w, o, d, cnt);
@@ -872,6 +879,7 @@ PT_FN void tile_list_build(const Mem& mem, const SceneLayout& L, const Camera64&
     if (L.node_half) {
         for (uint32_t si = 0; si < L.n_spheres && !overflow; si++) offer(si);
     } else {
+        if (L.n_hoisted) offer(L.n_spheres - 1u);  // in no leaf: the walk below cannot find it
         constexpr int STACK = 64;
         int32_t stack[STACK];
         int sp = 0;

@@ -98,6 +98,9 @@ struct SceneLayout {
     uint32_t off_glass, n_glass;      // f4[]  (ir, 1 / ir, r0(ir), r0(1 / ir)), see glass_record
     uint32_t total_bytes;
     uint32_t max_depth;               // deepest interior-node chain; bounds the traversal stack
+    uint32_t n_hoisted;               // 1: the last sphere of the leaf order is in no leaf; every ray that walks the
+                                      // tree tests it first (a sphere far larger than everything else -- the ground
+                                      // of every shipped scene -- whose box no ray of the scene misses)
 };
 
 #if defined(__HIPCC__)

@@ -231,6 +231,7 @@ bool pack_scene(const SceneArrays& a, bool reference_topology, const Node48* ref
         L.box_org[0] = org[0], L.box_org[1] = org[1], L.box_org[2] = org[2];
     }
     L.max_depth = bvh.max_depth;
+    L.n_hoisted = bvh.n_hoisted;
     L.reference_walk = reference_walk ? 1u : 0u;
     const size_t off = L.total_bytes;
     blob.assign(off, 0);

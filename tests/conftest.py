@@ -132,7 +132,7 @@ def emul():
     return L
 
 
-SCENE_LAYOUT_BYTES = 80   # sizeof(pt::SceneLayout) (pt_types.h); the library and the harness both check it
+SCENE_LAYOUT_BYTES = 84   # sizeof(pt::SceneLayout) (pt_types.h); the library and the harness both check it
 
 
 def device_scene_blob(renderer):

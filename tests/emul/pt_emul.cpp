@@ -95,6 +95,7 @@ int emul_check_blob_tree() {
             }
         }
     }
+    if (L.n_hoisted) seen_sphere[L.n_spheres - 1u]++;  // in no leaf on purpose
     for (uint8_t v : seen_node) if (v != 1) return 7;
     for (uint8_t v : seen_sphere) if (v != 1) return 8;
     if (deepest > L.max_depth) return 9;
@@ -312,6 +313,7 @@ int emul_check_top_first(const void* spheres32, size_t n, uint32_t k_top) {
             }
         }
     }
+    if (bvh.n_hoisted) seen_sphere[bvh.order.back()]++;  // in no leaf on purpose
     for (uint8_t v : seen_node) if (v != 1) return 7;
     for (uint8_t v : seen_sphere) if (v != 1) return 8;
     if (deepest != depth_before) return 9;
