@@ -435,6 +435,18 @@ bool from_reference(const Node48* nodes, uint32_t n_nodes, uint32_t n_spheres, B
     return true;
 }
 
+uint32_t pick_hoisted(const Sphere32* spheres, uint32_t n) {
+    const char* e = getenv("MI355PT_HOIST");
+    if (n < 8 || (e && atoi(e) == 0)) return n;  // a handful of spheres gains nothing (scene2's four: 3 % slower)
+    uint32_t big = 0;
+    for (uint32_t i = 1; i < n; i++)
+        if (spheres[i].rad > spheres[big].rad) big = i;
+    Box rest = empty_box();
+    for (uint32_t i = 0; i < n; i++)
+        if (i != big) rest = unite(rest, sphere_box(spheres[i]));
+    return half_area(sphere_box(spheres[big])) >= 4.0f * half_area(rest) ? big : n;
+}
+
 bool build_sah(const Sphere32* spheres, uint32_t n, Bvh2& out, std::string& err) {
     out = Bvh2{};
     if (n < 2) {
@@ -448,21 +460,9 @@ bool build_sah(const Sphere32* spheres, uint32_t n, Bvh2& out, std::string& err)
     // A sphere far larger than the rest of the scene together (the ground of every shipped scene: radius 1000
     // under spheres within a dozen units) is kept out of the tree: as a leaf under the root its box would be
     // entered by nearly every ray, each paying a node visit and a leaf step to reach it; the walks test it first
-    // instead, which also gives them a closest hit to cull against from the first node on.  MI355PT_HOIST=0: off.
+    // instead, which also gives them a closest hit to cull against from the first node on.
     const uint32_t n_all = n;
-    uint32_t hoisted = n_all;  // none
-    {
-        const char* e = getenv("MI355PT_HOIST");
-        if (n >= 8 && !(e && atoi(e) == 0)) {  // a handful of spheres gains nothing (scene2's four: 3 % slower)
-            uint32_t big = 0;
-            for (uint32_t i = 1; i < n; i++)
-                if (spheres[i].rad > spheres[big].rad) big = i;
-            Box rest = empty_box();
-            for (uint32_t i = 0; i < n; i++)
-                if (i != big) rest = unite(rest, sphere_box(spheres[i]));
-            if (half_area(sphere_box(spheres[big])) >= 4.0f * half_area(rest)) hoisted = big;
-        }
-    }
+    const uint32_t hoisted = pick_hoisted(spheres, n);  // n_all: none
     SahBuilder b;
     b.prims.reserve(n);
     for (uint32_t i = 0; i < n; i++) {

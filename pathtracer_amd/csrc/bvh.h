@@ -20,6 +20,10 @@ struct Bvh2 {
     uint32_t n_hoisted = 0;       // 1: order.back() is in no leaf (SceneLayout::n_hoisted)
 };
 
+// The sphere that stays out of the tree (SceneLayout::n_hoisted), or n when there is none: the largest one, if its
+// padded box has at least four times the surface of the box around all the others.  MI355PT_HOIST=0: none.
+uint32_t pick_hoisted(const Sphere32* spheres, uint32_t n);
+
 // Renumbers the interior nodes: the first min(k_top, n) indices go to the nodes with the largest
 // boxes, parents before children (every prefix is a connected top of the tree); the rest follow in
 // depth-first order.  The root stays node 0; leaf links and the sphere order are unchanged.

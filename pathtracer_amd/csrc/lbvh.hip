@@ -16,6 +16,7 @@
 
 #include "gpu.h"
 #include "gpu_state.h"
+#include "bvh.h"
 #include "scene_pack.h"
 #include "pt_device.h"
 
@@ -257,15 +258,29 @@ __global__ void lbvh_tie_ranks(const uint32_t* by_z, uint32_t n, uint32_t* tie_r
     tie_rank[n < 4u ? p : by_z[p]] = reference_leaf_rank(n, p);  // fewer than four spheres: the reference sorts nothing
 }
 
-// Spheres and their material words in leaf (= sorted) order.
-__global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, const uint32_t* tie_rank, uint32_t n, f4* out_spheres,
-                            u2* out_info) {
+// The spheres the tree is built over: all but the one that stays out of it (SceneLayout::n_hoisted).
+__global__ void lbvh_without(const Sphere32* spheres, uint32_t n, uint32_t hoisted, Sphere32* out) {
+    const uint32_t i = blockIdx.x * BLK + threadIdx.x;
+    if (i + 1u < n) out[i] = spheres[i < hoisted ? i : i + 1u];
+}
+
+// Spheres and their material words in leaf (= sorted) order; the sphere that is in no leaf comes last.  `order`
+// indexes the array the tree was built over (lbvh_without), `spheres` and `tie_rank` the scene's own.
+__global__ void lbvh_gather(const Sphere32* spheres, const uint32_t* order, const uint32_t* tie_rank, uint32_t n, uint32_t hoisted,
+                            f4* out_spheres, u2* out_info) {
     const uint32_t p = blockIdx.x * BLK + threadIdx.x;
     if (p >= n) return;
-    const Sphere32 s = spheres[order[p]];
+    uint32_t id;
+    if (hoisted < n) {
+        const uint32_t o = p + 1u < n ? order[p] : 0u;
+        id = p + 1u < n ? (o < hoisted ? o : o + 1u) : hoisted;
+    } else {
+        id = order[p];
+    }
+    const Sphere32 s = spheres[id];
     out_spheres[p] = f4{s.pos[0], s.pos[1], s.pos[2], s.rad * s.rad};
     const uint32_t type = s.mat_type > 3u ? 4u : s.mat_type;
-    out_info[p] = u2{type | (s.mat_index << 3), tie_rank[order[p]]};
+    out_info[p] = u2{type | (s.mat_index << 3), tie_rank[id]};
 }
 
 struct Scratch {  // device allocations of one build, released on every exit path
@@ -287,7 +302,9 @@ struct Scratch {  // device allocations of one build, released on every exit pat
 
 bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std::string& err) {
     if (!validate_scene(a, err)) return false;
-    const uint32_t n = (uint32_t)a.n_spheres;
+    const uint32_t n_all = (uint32_t)a.n_spheres;
+    const uint32_t hoisted = pick_hoisted(a.spheres, n_all);  // n_all: none
+    const uint32_t n = hoisted < n_all ? n_all - 1u : n_all;   // spheres the tree is built over
     DeviceGuard guard(d->id);
     PT_HIP(hipStreamSynchronize(d->stream));
     hipStream_t st = d->stream;
@@ -296,14 +313,14 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     int leaf_max = 2;
     if (const char* e = getenv("MI355PT_LBVH_LEAF")) leaf_max = std::min(std::max(atoi(e), 1), MAX_LEAF_SPHERES);
     Scratch tmp;
-    Sphere32* spheres;
+    Sphere32 *all_spheres, *spheres;  // the scene's own array; the one the tree is built over
     uint64_t *keys, *keys_sorted;
     uint32_t *vals, *order;
     int32_t *child0, *child1, *parent_of_node, *parent_of_leaf;
     int *arrived, *box, *max_depth, *kept_count;
     uint32_t *first_of, *count_of;
     float* node_box;
-    if (!tmp.get(&spheres, n) || !tmp.get(&keys, n) || !tmp.get(&keys_sorted, n) || !tmp.get(&vals, n) ||
+    if (!tmp.get(&all_spheres, n_all) || (hoisted < n_all && !tmp.get(&spheres, n)) || !tmp.get(&keys, n) || !tmp.get(&keys_sorted, n) || !tmp.get(&vals, n) ||
         !tmp.get(&order, n) || !tmp.get(&child0, n) || !tmp.get(&child1, n) || !tmp.get(&parent_of_node, n) ||
         !tmp.get(&parent_of_leaf, n) || !tmp.get(&arrived, n) || !tmp.get(&box, 8) || !tmp.get(&max_depth, 1) ||
         !tmp.get(&kept_count, 1) || !tmp.get(&first_of, n) || !tmp.get(&count_of, n) || !tmp.get(&node_box, (size_t)n * 6)) {
@@ -311,7 +328,8 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
         return false;
     }
     uint32_t *area_keys, *area_keys_sorted, *area_vals, *by_area, *below, *below_before, *new_id, *tie_rank;
-    if (!tmp.get(&tie_rank, n) || !tmp.get(&area_keys, n) || !tmp.get(&area_keys_sorted, n) || !tmp.get(&area_vals, n) || !tmp.get(&by_area, n) ||
+    if (!tmp.get(&tie_rank, n_all) || !tmp.get(&area_keys, n_all) || !tmp.get(&area_keys_sorted, n_all) || !tmp.get(&area_vals, n_all) ||
+        !tmp.get(&by_area, n_all) ||
         !tmp.get(&below, n) || !tmp.get(&below_before, n) || !tmp.get(&new_id, n)) {
         err = "lbvh: out of device memory";
         return false;
@@ -319,7 +337,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     const uint32_t n_nodes = n - 1u;
     size_t sort_bytes = 0, sort32_bytes = 0, scan_bytes = 0;
     PT_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys, keys_sorted, vals, order, n, 0, 64, st));
-    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n, 0, 32, st));
+    PT_HIP(rocprim::radix_sort_pairs(nullptr, sort32_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_all, 0, 32, st));
     PT_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, below, below_before, 0u, n_nodes, rocprim::plus<uint32_t>(), st));
     sort_bytes = std::max(sort_bytes, std::max(sort32_bytes, scan_bytes));
     char* sort_tmp;
@@ -330,18 +348,24 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     d->have_scene = false;
 
     const int box_init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
-    PT_HIP(hipMemcpyAsync(spheres, a.spheres, (size_t)n * sizeof(Sphere32), hipMemcpyHostToDevice, st));
+    PT_HIP(hipMemcpyAsync(all_spheres, a.spheres, (size_t)n_all * sizeof(Sphere32), hipMemcpyHostToDevice, st));
     PT_HIP(hipMemcpyAsync(box, box_init, sizeof box_init, hipMemcpyHostToDevice, st));
     PT_HIP(hipMemsetAsync(arrived, 0, (size_t)n * sizeof(int), st));
     PT_HIP(hipMemsetAsync(max_depth, 0, sizeof(int), st));
     PT_HIP(hipMemsetAsync(kept_count, 0, sizeof(int), st));
-    const dim3 grid((n + BLK - 1) / BLK), block(BLK);
-    // tie ranks first: the sort borrows the buffers of the later sort by box area
-    hipLaunchKernelGGL(lbvh_z_keys, grid, block, 0, st, spheres, n, area_keys, area_vals);
+    const dim3 grid_all((n_all + BLK - 1) / BLK), grid((n + BLK - 1) / BLK), block(BLK);
+    // tie ranks first, over the whole scene: the sort borrows the buffers of the later sort by box area
+    hipLaunchKernelGGL(lbvh_z_keys, grid_all, block, 0, st, all_spheres, n_all, area_keys, area_vals);
     PT_HIP(hipGetLastError());
-    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, area_keys, area_keys_sorted, area_vals, by_area, n, 0, 32, st));
-    hipLaunchKernelGGL(lbvh_tie_ranks, grid, block, 0, st, by_area, n, tie_rank);
+    PT_HIP(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, area_keys, area_keys_sorted, area_vals, by_area, n_all, 0, 32, st));
+    hipLaunchKernelGGL(lbvh_tie_ranks, grid_all, block, 0, st, by_area, n_all, tie_rank);
     PT_HIP(hipGetLastError());
+    if (hoisted < n_all) {
+        hipLaunchKernelGGL(lbvh_without, grid_all, block, 0, st, all_spheres, n_all, hoisted, spheres);
+        PT_HIP(hipGetLastError());
+    } else {
+        spheres = all_spheres;
+    }
     hipLaunchKernelGGL(lbvh_bounds, grid, block, 0, st, spheres, n, box);
     hipLaunchKernelGGL(lbvh_codes, grid, block, 0, st, spheres, n, box, keys, vals);
     PT_HIP(hipGetLastError());
@@ -383,7 +407,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     hipLaunchKernelGGL(lbvh_new_ids, grid, block, 0, st, by_area, below, below_before, (int)n_nodes, (int)top, new_id);
     hipLaunchKernelGGL(lbvh_emit, grid, block, 0, st, spheres, order, (int)n, child0, child1, node_box, new_id,
                        first_of, count_of, leaf_max, reinterpret_cast<Node64*>(d->scene + L.off_nodes));
-    hipLaunchKernelGGL(lbvh_gather, grid, block, 0, st, spheres, order, tie_rank, n, reinterpret_cast<f4*>(d->scene + L.off_spheres),
+    hipLaunchKernelGGL(lbvh_gather, grid_all, block, 0, st, all_spheres, order, tie_rank, n_all, hoisted, reinterpret_cast<f4*>(d->scene + L.off_spheres),
                        reinterpret_cast<u2*>(d->scene + L.off_info));
     PT_HIP(hipGetLastError());
     if (a.n_lights) PT_HIP(hipMemcpyAsync(d->scene + L.off_lights, a.lights, a.n_lights * 16, hipMemcpyHostToDevice, st));
@@ -397,6 +421,7 @@ bool build_scene_lbvh(Device* d, const SceneArrays& a, SceneLayout& layout, std:
     PT_HIP(hipMemcpyAsync(&depth, max_depth, sizeof depth, hipMemcpyDeviceToHost, st));
     PT_HIP(hipStreamSynchronize(st));
     L.max_depth = (uint32_t)std::max(1, depth);
+    L.n_hoisted = hoisted < n_all ? 1u : 0u;
     layout = L;
     return adopt_layout(d, L, err);
 }
