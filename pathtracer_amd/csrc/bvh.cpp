@@ -444,7 +444,10 @@ uint32_t pick_hoisted(const Sphere32* spheres, uint32_t n) {
     Box rest = empty_box();
     for (uint32_t i = 0; i < n; i++)
         if (i != big) rest = unite(rest, sphere_box(spheres[i]));
-    return half_area(sphere_box(spheres[big])) >= 4.0f * half_area(rest) ? big : n;
+    const Box bb = sphere_box(spheres[big]);
+    for (int a = 0; a < 3; a++)  // it has to touch the rest of the scene: a huge sphere far away is entered by few rays
+        if (bb.mn[a] > rest.mx[a] || bb.mx[a] < rest.mn[a]) return n;
+    return half_area(bb) >= 4.0f * half_area(rest) ? big : n;
 }
 
 bool build_sah(const Sphere32* spheres, uint32_t n, Bvh2& out, std::string& err) {

@@ -21,7 +21,8 @@ struct Bvh2 {
 };
 
 // The sphere that stays out of the tree (SceneLayout::n_hoisted), or n when there is none: the largest one, if its
-// padded box has at least four times the surface of the box around all the others.  MI355PT_HOIST=0: none.
+// padded box has at least four times the surface of the box around all the others and meets that box (scenes of at
+// least eight spheres).  MI355PT_HOIST=0: none.
 uint32_t pick_hoisted(const Sphere32* spheres, uint32_t n);
 
 // Renumbers the interior nodes: the first min(k_top, n) indices go to the nodes with the largest

@@ -29,6 +29,7 @@ uint32_t g_tile_list_max = TILE_LIST_CAP;
 uint64_t g_list_rays = 0, g_list_tests = 0, g_walk_tiles = 0, g_list_tiles = 0;
 bool g_log = true;
 const bool g_trace = getenv("PT_EMUL_TRACE") != nullptr;  // every ray of every path to stderr (debugging aid)
+uint32_t g_last_hoisted = 0;  // SceneLayout::n_hoisted of the last emul_render
 std::vector<char> g_blob;   // a packed scene read back from the device (emul_set_blob): rendered instead of the harness's own packing
 SceneLayout g_blob_layout;
 }  // namespace
@@ -130,6 +131,7 @@ int emul_render(const void* spheres32, size_t n_spheres, const void* lights, siz
     } else if (!pack_scene(a, reference_topology != 0, (const Node48*)ref_nodes, n_ref_nodes, blob, L, bvh, g_err)) {
         return -1;
     }
+    g_last_hoisted = L.n_hoisted;
     if (bvh_info) bvh_info[0] = (uint32_t)bvh.nodes.size(), bvh_info[1] = bvh.max_depth, bvh_info[2] = L.total_bytes, bvh_info[3] = L.node_half;
     PtrMem mem{blob.data()};
     // A float-node scene that the device would stage in LDS is walked there through direction-ordered
@@ -351,6 +353,7 @@ int emul_tile_lists(const void* spheres32, size_t n_spheres, const void* lights,
     return 0;
 }
 
+uint32_t emul_last_hoisted() { return g_last_hoisted; }
 uint32_t emul_reference_leaf_rank(uint32_t n, uint32_t pos) { return reference_leaf_rank(n, pos); }
 uint32_t emul_pixel_hash(uint32_t px, uint32_t py, uint32_t w, uint32_t h) { return pixel_hash(px, py, w, h); }
 float emul_det_sin(float x) { return det_sin(x); }

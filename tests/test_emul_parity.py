@@ -357,3 +357,49 @@ def test_tie_rank_formula_equals_the_reference_tree(emul, pa):
         want = np.zeros(n, np.int64)
         want[leaves] = np.arange(n)
         assert (got == want).all(), n
+
+
+def test_sphere_kept_out_of_the_tree(emul, orc, pa, monkeypatch):
+    # The sphere far larger than the rest of the scene (the ground of every shipped scene) is in no leaf: every
+    # walk tests it first, the candidate lists offer it to every tile.  Same bits with and without; not done for a
+    # handful of spheres, nor for a huge sphere that does not touch the rest of the scene.
+    W, H = 96, 54
+    for name, want in (("scene1", 1), ("scene3", 1), ("scene2", 0)):
+        sc = pa.load_ron_scene(os.path.join(FIXTURES, name + ".ron"))
+        osc = oracle_scene(orc, sc)
+        cam = osc.camera(W, H)
+        ref, st = orc.render(osc, cam, W, H, SEEDS)
+        acc, cnt, _ = emul.render(sc, cam, W, H, SEEDS)
+        assert emul.emul_last_hoisted() == want and bits_equal(ref, acc) and cnt["rays"] == st["rays"]
+        if want:
+            monkeypatch.setenv("MI355PT_HOIST", "0")
+            off, cnt_off, _ = emul.render(sc, cam, W, H, SEEDS)
+            monkeypatch.delenv("MI355PT_HOIST")
+            assert emul.emul_last_hoisted() == 0 and bits_equal(ref, off)
+            assert cnt["nodes"] < cnt_off["nodes"]          # one node visit less per walk, at least
+    # the ground doubled (equal roots in every ground hit: the tie rank decides): neither copy is far larger than
+    # the rest of the scene, so both stay in the tree
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene3.ron"))
+    sp = np.zeros(len(sc.spheres) + 1, pa.renderer.SPHERE_DT)
+    sp[:-1] = sc.spheres
+    ground = int(np.argmax(sc.spheres["rad"]))
+    sp[-1] = sc.spheres[ground]
+    sp[-1]["mat_type"] = 2 if sc.spheres[ground]["mat_type"] != 2 else 1
+    sp[-1]["mat_index"] = 0
+    sc.spheres = sp
+    osc = oracle_scene(orc, sc)
+    cam = osc.camera(W, H)
+    ref, _ = orc.render(osc, cam, W, H, SEEDS)
+    acc, _, _ = emul.render(sc, cam, W, H, SEEDS)
+    assert emul.emul_last_hoisted() == 0 and bits_equal(ref, acc)
+    # a huge sphere that the scene does not touch stays in the tree
+    sc = pa.load_ron_scene(os.path.join(FIXTURES, "scene1.ron"))
+    sp = sc.spheres.copy()
+    ground = int(np.argmax(sp["rad"]))
+    sp["pos"][ground] = (0.0, -5000.0, 0.0)
+    sc.spheres = sp
+    osc = oracle_scene(orc, sc)
+    cam = osc.camera(W, H)
+    ref, _ = orc.render(osc, cam, W, H, SEEDS[:1])
+    acc, _, _ = emul.render(sc, cam, W, H, SEEDS[:1])
+    assert emul.emul_last_hoisted() == 0 and bits_equal(ref, acc)

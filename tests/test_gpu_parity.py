@@ -437,6 +437,22 @@ def test_tree_built_on_the_gpu_is_sound_and_breaks_ties_like_the_reference(pa, o
             emul.set_blob(None)
 
 
+@pytest.mark.parametrize("mode", ["sah", "lbvh"])
+def test_sphere_kept_out_of_the_tree(pa, orc, monkeypatch, mode):
+    # the ground sphere is in no leaf and every walk tests it first (host builder and GPU builder): same bits as with
+    # it in the tree and as the oracle, fewer node visits
+    bvh = pa.BVH_SAH if mode == "sah" else pa.BVH_LBVH
+    path = os.path.join(FIXTURES, "scene1.ron")
+    sc, osc = pa.load_ron_scene(path), orc.Scene.from_ron(path)
+    W, H = 200, 117
+    ref, st = orc.render(osc, osc.camera(W, H), W, H, SEEDS, threads=16)
+    acc, gs = gpu_render(pa, sc, W, H, SEEDS, bvh_mode=bvh, flags=pa.FLAG_COUNT)
+    monkeypatch.setenv("MI355PT_HOIST", "0")
+    off, gs_off = gpu_render(pa, sc, W, H, SEEDS, bvh_mode=bvh, flags=pa.FLAG_COUNT)
+    assert bits_equal(ref, acc) and bits_equal(ref, off) and gs["rays"] == gs_off["rays"] == st["rays"]
+    assert gs["nodes"] < gs_off["nodes"] and gs["bvh_nodes"] <= gs_off["bvh_nodes"]
+
+
 def test_tree_built_on_the_gpu_large(pa, orc):
     from pathtracer_amd import synth
     sc = synth.plane_scene(200_000)
